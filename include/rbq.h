@@ -1,0 +1,159 @@
+/*
+ * rbq.h — C ABI of the MI355X-native IVF+RaBitQ candidate-scan engine.
+ *
+ * This is the drop-in boundary for ONE path of lqhl/rabitq-rs: the query-time
+ * scan `IvfRabitqIndex::search` / `batch_search` / `search_filtered`
+ * (reference src/ivf.rs:1705-1752) whose body is `search_fastscan`
+ * (src/ivf.rs:1754-1895) + `search_cluster_v2_batched` (src/ivf.rs:1901-2129).
+ * Everything from `rotator.rotate(query)` to the sorted result vector runs on
+ * the GPU behind `rbq_search_batch`.  Index training stays with the caller.
+ *
+ * The reference has no FFI seam of its own (search_fastscan is a private
+ * method over private fields, src/ivf.rs:935-946), so the boundary is cut at
+ * the two places a maintainer can reach without touching the algorithm:
+ *   - the in-memory `ClusterData` arrays (src/ivf.rs:205-242) -> rbq_index_create
+ *   - the persisted RBQ1-v3 byte stream (src/ivf.rs:1317-1474) -> rbq_index_load_rbq1
+ * INTEGRATION.md shows the Rust-side `extern "C"` binding for both.
+ *
+ * Plain pointers and sizes only; no torch / HIP types in any signature.
+ */
+#ifndef RBQ_H
+#define RBQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: 1:1 with `RabitqError` (reference src/lib.rs:39-57) ---- */
+#define RBQ_OK                   0
+#define RBQ_DIMENSION_MISMATCH   1 /* RabitqError::DimensionMismatch{expected,got} */
+#define RBQ_INVALID_CONFIG       2 /* RabitqError::InvalidConfig(msg)             */
+#define RBQ_EMPTY_INDEX          3 /* RabitqError::EmptyIndex                     */
+#define RBQ_IO                   4 /* RabitqError::Io                             */
+#define RBQ_INVALID_PERSISTENCE  5 /* RabitqError::InvalidPersistence(msg)        */
+#define RBQ_DEVICE               6 /* hipError_t / launch failure (new: no CPU fallback exists) */
+
+#define RBQ_METRIC_L2 0            /* metric_to_tag, src/ivf.rs:122-127 */
+#define RBQ_METRIC_IP 1
+#define RBQ_ROTATOR_MATRIX 0       /* RotatorType, src/rotation.rs:10-15 */
+#define RBQ_ROTATOR_FHT_KAC 1
+
+/* FASTSCAN_BATCH_SIZE, src/simd.rs:768 */
+#define RBQ_BATCH 32
+
+typedef struct rbq_index rbq_index; /* opaque; owns device memory */
+
+/* Mirrors the scalar fields of `IvfRabitqIndex` (src/ivf.rs:935-946) and the
+ * RBQ1-v3 header (src/ivf.rs:1324-1373). */
+typedef struct {
+    uint32_t dim;          /* query dimensionality                                  */
+    uint32_t padded_dim;   /* rotator.padded_dim(): dim rounded up to x64 for FhtKac */
+    uint8_t  metric;       /* RBQ_METRIC_*                                          */
+    uint8_t  rotator;      /* RBQ_ROTATOR_*                                         */
+    uint8_t  ex_bits;      /* total_bits-1; only 0, 2, 6 (src/simd.rs:3205-3215)    */
+    uint8_t  reserved;
+    uint64_t n_vectors;    /* sum of list sizes                                     */
+    uint64_t n_lists;      /* clusters.len()                                        */
+    const uint8_t* rotator_blob; /* DynamicRotator::serialize(): FhtKac = 4*D/8 flip
+                                    bytes (src/rotation.rs:486-489); Matrix = D*D f32 LE */
+    uint64_t rotator_len;
+} rbq_header;
+
+/* One `ClusterData` (src/ivf.rs:205-242), borrowed for the duration of the call. */
+typedef struct {
+    const float*    centroid;     /* [padded_dim], rotated space                     */
+    uint64_t        n;            /* num_vectors                                     */
+    const uint64_t* ids;          /* [n]                                             */
+    const uint8_t*  batch_data;   /* exactly ClusterData.batch_data: ceil(n/32) records
+                                     of [D*4 B FastScan codes | f_add[32] | f_rescale[32]
+                                     | f_error[32]] (src/ivf.rs:247-316)             */
+    uint64_t        batch_len;    /* ceil(n/32) * (D*4 + 384)                        */
+    const uint8_t*  ex_codes;     /* [n][D*ex_bits/8] flattened ex_codes_packed; may be
+                                     NULL when ex_bits == 0                          */
+    const float*    f_add_ex;     /* [n] (ignored when ex_bits == 0)                 */
+    const float*    f_rescale_ex; /* [n]                                             */
+} rbq_list_view;
+
+/* `SearchDiagnostics` (src/ivf.rs:150-155), one per query. */
+typedef struct {
+    uint64_t estimated;
+    uint64_t skipped_by_lower_bound;
+    uint64_t extended_evaluations;
+} rbq_diag;
+
+/* Build a device-resident index from ClusterData-shaped host arrays.
+ * n_devices must be 1 in this version; devices[0] is the HIP device ordinal
+ * (NULL = current device). Inputs are copied; nothing is retained. */
+int rbq_index_create(const rbq_header* hdr, const rbq_list_view* lists,
+                     int n_devices, const int* devices, rbq_index** out);
+
+/* Build a device-resident index straight from an RBQ1 v3 byte stream as
+ * written by `IvfRabitqIndex::save_to_writer` (src/ivf.rs:1317-1474); applies
+ * the same validation as `load_from_reader` (src/ivf.rs:1484-1702) incl. CRC32. */
+int rbq_index_load_rbq1(const void* bytes, size_t len,
+                        int n_devices, const int* devices, rbq_index** out);
+
+void rbq_index_destroy(rbq_index* idx);
+
+/* Accessors (IvfRabitqIndex::len / cluster_count, src/ivf.rs:1218-1230). */
+uint64_t rbq_index_len(const rbq_index* idx);
+uint64_t rbq_index_cluster_count(const rbq_index* idx);
+uint32_t rbq_index_dim(const rbq_index* idx);
+uint32_t rbq_index_padded_dim(const rbq_index* idx);
+
+/* `batch_search` (src/ivf.rs:1743-1752); nq = 1 is `search` (:1705);
+ * filter_words != NULL is `search_filtered` (:1723): a dense bitset over the
+ * u32 id space, bit i set <=> RoaringBitmap::contains(i) (src/ivf.rs:2018-2022).
+ *
+ * queries:    [nq][query_dim] row-major host f32
+ * out_ids:    [nq][top_k]  (unused slots = UINT64_MAX)
+ * out_scores: [nq][top_k]  (unused slots = NaN); L2: distance asc, IP: score desc
+ * out_counts: [nq]         number of valid results of each query (<= top_k)
+ * diag:       NULL or [nq]
+ *
+ * Errors follow search_fastscan: EMPTY_INDEX is checked before
+ * DIMENSION_MISMATCH (src/ivf.rs:1761-1769); top_k == 0 returns RBQ_OK with all
+ * counts 0 (:1792-1794); nprobe is clamped to [1, n_lists] (:1791).
+ * Re-entrant on one handle. */
+int rbq_search_batch(const rbq_index* idx, const float* queries, uint64_t nq,
+                     uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
+                     const uint32_t* filter_words, uint64_t filter_nbits,
+                     uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
+                     rbq_diag* diag);
+
+/* Same operation on DEVICE pointers (queries and outputs already in HBM of the
+ * index's device), enqueued on `hip_stream` (a hipStream_t passed as void*,
+ * NULL = default stream) without host synchronisation. d_filter_words may be
+ * NULL. d_diag is NULL or [nq] rbq_diag in device memory. */
+int rbq_search_batch_device(const rbq_index* idx, const float* d_queries, uint64_t nq,
+                            uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
+                            const uint32_t* d_filter_words, uint64_t filter_nbits,
+                            uint64_t* d_out_ids, float* d_out_scores,
+                            uint32_t* d_out_counts, rbq_diag* d_diag,
+                            void* hip_stream);
+
+/* Timing taps for bench.py: average duration (ms) of each stage kernel between
+ * rbq_profile_begin/end, measured with hipEvents on the stream the kernels run
+ * on. stage names: "prep", "rank", "scan". Returns <0 for an unknown stage. */
+void   rbq_profile_begin(rbq_index* idx);
+void   rbq_profile_end(rbq_index* idx);
+double rbq_profile_stage_ms(const rbq_index* idx, const char* stage, uint64_t* launches);
+/* Algorithmic bytes (sum over probed lists of n_c*(D/8+12)) of the
+ * scan launches between rbq_profile_begin/end. */
+uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
+
+const char* rbq_strerror(int code);
+/* Copies the calling thread's last error detail (e.g. "checksum mismatch",
+ * "expected 960, got 128") into buf; returns its full length. */
+int rbq_last_error_detail(char* buf, size_t n);
+
+/* Library/ABI version (major<<16 | minor). */
+uint32_t rbq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBQ_H */

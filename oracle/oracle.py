@@ -1,0 +1,136 @@
+"""ctypes binding of the CPU oracle (oracle/librbq_ref.so). TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the
+product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "librbq_ref.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        f32p, u8p, vp = C.c_void_p, C.c_void_p, C.c_void_p
+        L.ref_dot.restype = C.c_float
+        L.ref_dot.argtypes = [f32p, f32p, C.c_size_t]
+        L.ref_l2_distance_sqr.restype = C.c_float
+        L.ref_l2_distance_sqr.argtypes = [f32p, f32p, C.c_size_t]
+        L.ref_floor_log2.restype = C.c_uint32
+        L.ref_floor_log2.argtypes = [C.c_uint64]
+        L.ref_padded_dim.restype = C.c_uint32
+        L.ref_padded_dim.argtypes = [C.c_uint32, C.c_int]
+        L.ref_fht.argtypes = [f32p, C.c_size_t]
+        L.ref_fht_kac_rotate.argtypes = [C.c_uint32, C.c_uint32, u8p, f32p, f32p]
+        L.ref_matrix_rotate.argtypes = [C.c_uint32, C.c_uint32, f32p, f32p, f32p]
+        L.ref_rotate.argtypes = [vp, f32p, f32p]
+        L.ref_pack_lut_f32.argtypes = [f32p, C.c_size_t, f32p]
+        L.ref_query_lut.argtypes = [f32p, C.c_size_t, u8p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ref_query_precompute.argtypes = [f32p, C.c_size_t, C.c_uint32, vp]
+        for n in ("ref_accumulate_batch_scalar", "ref_accumulate_batch_shuffle_emul", "ref_accumulate_batch"):
+            getattr(L, n).argtypes = [u8p, u8p, C.c_size_t, vp]
+        L.ref_simd_level.restype = C.c_int
+        L.ref_force_simd_level.argtypes = [C.c_int]
+        L.ref_unpack_single_vector_bytes.argtypes = [u8p, C.c_int, C.c_size_t, u8p]
+        L.ref_compute_batch_distances.argtypes = [vp, C.c_float, C.c_float, f32p, f32p, f32p,
+                                                  C.c_float, C.c_float, C.c_float, f32p, f32p, f32p]
+        for n in ("ref_ip_packed_ex2", "ref_ip_packed_ex6"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [f32p, u8p, C.c_size_t]
+        L.ref_ex_dot.restype = C.c_float
+        L.ref_ex_dot.argtypes = [f32p, u8p, C.c_size_t, C.c_uint32]
+        L.ref_select_probes.restype = C.c_size_t
+        L.ref_select_probes.argtypes = [vp, vp, f32p, C.c_uint32, vp]
+        L.ref_search.restype = C.c_int
+        L.ref_search.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64,
+                                 vp, vp, vp, vp]
+        L.ref_search_batch.restype = C.c_int
+        L.ref_search_batch.argtypes = [vp, vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
+                                       C.c_uint64, vp, vp, vp, vp, C.c_int]
+        L.ref_num_threads.restype = C.c_int
+        L.ref_search_naive.restype = C.c_int
+        L.ref_search_naive.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+        _LIB = L
+    return _LIB
+
+
+class QueryConsts(C.Structure):
+    _fields_ = [("sum_q", C.c_float), ("query_norm", C.c_float), ("k1x_sum_q", C.c_float),
+                ("kbx_sum_q", C.c_float), ("binary_scale", C.c_float)]
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def _addr(ptr):
+    return C.cast(ptr, C.c_void_p)
+
+
+def search_batch(built, queries, top_k, nprobe, filter_words=None, filter_nbits=0, want_diag=False,
+                 nthreads=0):
+    """Oracle `batch_search` over a builder.BuiltIndex (or anything with hdr_ptr/lists_ptr).
+    Returns (rc, ids[nq,k] u64, scores[nq,k] f32, counts[nq] u32, diag[nq,3] u64 | None)."""
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    if q.ndim == 1:
+        q = q[None, :]
+    nq, qd = q.shape
+    ids = np.full((nq, max(top_k, 1)), np.iinfo(np.uint64).max, np.uint64)[:, :top_k].copy()
+    scores = np.full((nq, top_k), np.nan, np.float32)
+    counts = np.zeros(nq, np.uint32)
+    diag = np.zeros((nq, 3), np.uint64) if want_diag else None
+    fw = np.ascontiguousarray(filter_words, dtype=np.uint32) if filter_words is not None else None
+    rc = lib().ref_search_batch(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(q), nq, qd, top_k, nprobe,
+                                _p(fw), filter_nbits, _p(ids), _p(scores), _p(counts), _p(diag), nthreads)
+    return rc, ids, scores, counts, diag
+
+
+def search_naive(built, query, top_k, nprobe):
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    ids = np.zeros(top_k, np.uint64)
+    scores = np.zeros(top_k, np.float32)
+    cnt = C.c_uint32()
+    rc = lib().ref_search_naive(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(q), q.shape[0], top_k, nprobe,
+                                _p(ids), _p(scores), C.byref(cnt))
+    return rc, ids[:cnt.value], scores[:cnt.value]
+
+
+def rotate(built, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(built.padded_dim, np.float32)
+    lib().ref_rotate(_addr(built.hdr_ptr), _p(x), _p(out))
+    return out
+
+
+def query_lut(rq):
+    rq = np.ascontiguousarray(rq, dtype=np.float32)
+    D = rq.shape[0]
+    lut = np.empty(4 * D, np.uint8)
+    d, s = C.c_float(), C.c_float()
+    lib().ref_query_lut(_p(rq), D, _p(lut), C.byref(d), C.byref(s))
+    return lut, d.value, s.value
+
+
+def query_precompute(rq, ex_bits):
+    rq = np.ascontiguousarray(rq, dtype=np.float32)
+    qc = QueryConsts()
+    lib().ref_query_precompute(_p(rq), rq.shape[0], ex_bits, C.byref(qc))
+    return qc
+
+
+def select_probes(built, rq, nprobe):
+    rq = np.ascontiguousarray(rq, dtype=np.float32)
+    out = np.empty(built.n_lists, np.uint32)
+    n = lib().ref_select_probes(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(rq), nprobe, _p(out))
+    return out[:n].copy()

@@ -1,0 +1,210 @@
+"""`IvfRabitqIndex` query façade over the C ABI (include/rbq.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+LIB_PATH = os.path.join(_HERE, "csrc", "librbq.so")
+
+
+def lib():
+    """Load csrc/librbq.so (HIP, gfx950). Fails loudly — there is no CPU fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} missing: the HIP extension must be built first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.rbq_index_create.restype = C.c_int
+        L.rbq_index_create.argtypes = [vp, vp, C.c_int, vp, C.POINTER(vp)]
+        L.rbq_index_load_rbq1.restype = C.c_int
+        L.rbq_index_load_rbq1.argtypes = [vp, C.c_size_t, C.c_int, vp, C.POINTER(vp)]
+        L.rbq_index_destroy.argtypes = [vp]
+        for n in ("rbq_index_len", "rbq_index_cluster_count"):
+            getattr(L, n).restype = C.c_uint64
+            getattr(L, n).argtypes = [vp]
+        for n in ("rbq_index_dim", "rbq_index_padded_dim"):
+            getattr(L, n).restype = C.c_uint32
+            getattr(L, n).argtypes = [vp]
+        L.rbq_search_batch.restype = C.c_int
+        L.rbq_search_batch.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64,
+                                       vp, vp, vp, vp]
+        L.rbq_search_batch_device.restype = C.c_int
+        L.rbq_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
+                                              C.c_uint64, vp, vp, vp, vp, vp]
+        L.rbq_profile_begin.argtypes = [vp]
+        L.rbq_profile_end.argtypes = [vp]
+        L.rbq_profile_stage_ms.restype = C.c_double
+        L.rbq_profile_stage_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
+        L.rbq_profile_scan_bytes.restype = C.c_uint64
+        L.rbq_profile_scan_bytes.argtypes = [vp]
+        L.rbq_strerror.restype = C.c_char_p
+        L.rbq_strerror.argtypes = [C.c_int]
+        L.rbq_last_error_detail.restype = C.c_int
+        L.rbq_last_error_detail.argtypes = [C.c_char_p, C.c_size_t]
+        L.rbq_abi_version.restype = C.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _detail():
+    buf = C.create_string_buffer(512)
+    lib().rbq_last_error_detail(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def _check(rc):
+    if rc != _abi.RBQ_OK:
+        from . import RabitqError
+        raise RabitqError(rc, _detail())
+
+
+def _addr(ptr):
+    return C.cast(ptr, C.c_void_p)
+
+
+class IvfRabitqIndex:
+    """Device-resident IVF+RaBitQ index; query methods mirror reference src/ivf.rs:1705-1752."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # -- construction -------------------------------------------------------------
+    @classmethod
+    def from_built(cls, built, device=None):
+        """Upload a builder.BuiltIndex (ClusterData-shaped host arrays) via rbq_index_create."""
+        h = C.c_void_p()
+        dev = (C.c_int * 1)(device) if device is not None else None
+        _check(lib().rbq_index_create(_addr(built.hdr_ptr), _addr(built.lists_ptr), 1, dev, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_from_bytes(cls, data, device=None):
+        """`load_from_reader` (src/ivf.rs:1484-1702) straight into HBM."""
+        h = C.c_void_p()
+        dev = (C.c_int * 1)(device) if device is not None else None
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        _check(lib().rbq_index_load_rbq1(buf, len(data), 1, dev, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load_from_path(cls, path, device=None):
+        try:
+            with open(path, "rb") as f:
+                data = f.read()
+        except OSError as e:
+            from . import RabitqError
+            raise RabitqError(_abi.RBQ_IO, str(e))
+        return cls.load_from_bytes(data, device)
+
+    # -- accessors ----------------------------------------------------------------
+    def __len__(self):
+        return lib().rbq_index_len(self._h)
+
+    def is_empty(self):
+        return len(self) == 0
+
+    def cluster_count(self):
+        return lib().rbq_index_cluster_count(self._h)
+
+    @property
+    def dim(self):
+        return lib().rbq_index_dim(self._h)
+
+    @property
+    def padded_dim(self):
+        return lib().rbq_index_padded_dim(self._h)
+
+    # -- queries ------------------------------------------------------------------
+    def batch_search_raw(self, queries, params, filter_words=None, filter_nbits=0, want_diag=False):
+        """Returns (ids[nq,k] u64, scores[nq,k] f32, counts[nq] u32, diag[nq,3] u64|None)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq, qd = q.shape
+        k = params.top_k
+        ids = np.empty((nq, k), np.uint64)
+        scores = np.empty((nq, k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        diag = np.zeros((nq, 3), np.uint64) if want_diag else None
+        fw = np.ascontiguousarray(filter_words, dtype=np.uint32) if filter_words is not None else None
+        rc = lib().rbq_search_batch(self._h, q.ctypes.data, nq, qd, k, params.nprobe,
+                                    fw.ctypes.data if fw is not None else None, filter_nbits,
+                                    ids.ctypes.data, scores.ctypes.data, counts.ctypes.data,
+                                    diag.ctypes.data if diag is not None else None)
+        _check(rc)
+        return ids, scores, counts, diag
+
+    def _results(self, ids, scores, counts, q):
+        from . import SearchResult
+        return [SearchResult(int(ids[q, i]), float(scores[q, i])) for i in range(int(counts[q]))]
+
+    def search(self, query, params):
+        """`IvfRabitqIndex::search` (src/ivf.rs:1705-1711)."""
+        ids, scores, counts, _ = self.batch_search_raw(np.asarray(query, np.float32)[None, :], params)
+        return self._results(ids, scores, counts, 0)
+
+    def search_filtered(self, query, params, allowed_ids):
+        """`search_filtered` (src/ivf.rs:1723-1730); `allowed_ids` plays the RoaringBitmap."""
+        allowed = np.asarray(sorted(set(int(i) for i in allowed_ids)), dtype=np.uint64)
+        nbits = int(allowed.max()) + 1 if allowed.size else 0
+        words = np.zeros((nbits + 31) // 32 or 1, np.uint32)
+        if allowed.size:
+            np.bitwise_or.at(words, (allowed >> np.uint64(5)).astype(np.int64),
+                             (np.uint32(1) << (allowed & np.uint64(31)).astype(np.uint32)))
+        ids, scores, counts, _ = self.batch_search_raw(np.asarray(query, np.float32)[None, :], params,
+                                                       words, nbits)
+        return self._results(ids, scores, counts, 0)
+
+    def batch_search(self, queries, params):
+        """`batch_search` (src/ivf.rs:1743-1752): per-query results in input order."""
+        ids, scores, counts, _ = self.batch_search_raw(queries, params)
+        return [self._results(ids, scores, counts, q) for q in range(ids.shape[0])]
+
+    def batch_query(self, queries, top_k, nprobe):
+        """Python-binding shape of the reference (`batch_query`, src/python_bindings.rs:593-665):
+        list of (k,2) f32 arrays [id, score] (ids cast to f32 exactly as the reference does)."""
+        from . import SearchParams
+        ids, scores, counts, _ = self.batch_search_raw(queries, SearchParams(top_k, nprobe))
+        out = []
+        for q in range(ids.shape[0]):
+            c = int(counts[q])
+            out.append(np.stack([ids[q, :c].astype(np.float32), scores[q, :c]], axis=1))
+        return out
+
+    # -- device-pointer entry (bench / torch interop) --------------------------------
+    def search_batch_device(self, d_queries, nq, query_dim, top_k, nprobe, d_ids, d_scores, d_counts,
+                            stream=None, d_filter=None, filter_nbits=0, d_diag=None):
+        _check(lib().rbq_search_batch_device(self._h, d_queries, nq, query_dim, top_k, nprobe, d_filter,
+                                             filter_nbits, d_ids, d_scores, d_counts, d_diag, stream))
+
+    def profile_begin(self):
+        lib().rbq_profile_begin(self._h)
+
+    def profile_end(self):
+        lib().rbq_profile_end(self._h)
+
+    def profile_stage(self, name):
+        n = C.c_uint64()
+        ms = lib().rbq_profile_stage_ms(self._h, name.encode(), C.byref(n))
+        return ms, n.value
+
+    def profile_scan_bytes(self):
+        return lib().rbq_profile_scan_bytes(self._h)
+
+    def close(self):
+        if self._h:
+            lib().rbq_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
