@@ -1,0 +1,839 @@
+// kernels.hpp — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the IVF+RaBitQ query path.
+//
+// Stages (one launch each per query batch):
+//   k_prep         rotate (FHT-Kac / matrix) + query constants + u8 LUT      ref: src/rotation.rs:350-401,
+//                                                                                 src/ivf.rs:798-845,862-878
+//   k_rank_scores  canonical-order query x centroid scores                   ref: src/ivf.rs:1782-1789, src/math.rs:154-245
+//   k_select       nprobe smallest (score,cid) keys, per-list g_add/g_error,
+//                  and the per-query block work list                         ref: src/ivf.rs:1791-1857
+//   k_scan         THE roofline kernel: streams the probed lists' sign codes,
+//                  u8-LUT accumulate from LDS, fused estimator epilogue,
+//                  lower-bound pruning, ex-code refine, exact sequential
+//                  top-k replay                                              ref: src/ivf.rs:1901-2129, src/simd.rs:972-1184,
+//                                                                                 :1835-1915,:2090-2140
+// All floating point follows the oracle's operation order; the library is compiled with
+// -ffp-contract=off and fuses only where the reference does (explicit fmaf).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rbq {
+
+constexpr int kThreads = 256;
+
+struct QueryConsts {
+    float delta, sum_vl, k1x, kbx, scale, qnorm, sum_q, pad;
+};
+struct ProbeInfo {
+    float g_add, g_err, dotqc;
+    uint32_t cid;
+};
+struct WorkItem {
+    uint32_t gblock;      // global 32-vector block index
+    uint32_t rank_nvalid; // (probe rank << 6) | number of real vectors in the block (1..32)
+};
+
+__device__ __forceinline__ int32_t total_key(float x) { // f32::total_cmp ordering key
+    int32_t i = __float_as_int(x);
+    return i ^ (int32_t)(((uint32_t)(i >> 31)) >> 1);
+}
+__device__ __forceinline__ float key_to_float(int32_t k) {
+    return __int_as_float(k ^ (int32_t)(((uint32_t)(k >> 31)) >> 1));
+}
+__device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+
+// ---------------------------------------------------------------------------------------------
+// k_prep: one workgroup per query.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fht_lds(float* a, uint32_t n, uint32_t tid) {
+    for (uint32_t h = 1, lg = 0; h < n; h <<= 1, ++lg) {
+        for (uint32_t i = tid; i < n / 2; i += kThreads) {
+            uint32_t j = ((i >> lg) << (lg + 1)) | (i & (h - 1));
+            float x = a[j], y = a[j + h];
+            a[j] = x + y;
+            a[j + h] = x - y;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ queries, uint32_t dim, uint32_t D,
+                                                   uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
+                                                   uint32_t trunc, float fac, uint32_t ex_bits,
+                                                   float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
+                                                   QueryConsts* __restrict__ consts) {
+    extern __shared__ __align__(16) float sm[];
+    float* x = sm;         // [D]
+    float* y = sm + D;     // [D] (matrix rotator input)
+    __shared__ int s_kmin, s_kmax;
+    __shared__ float s_sum, s_n2;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const float* qin = queries + (size_t)q * dim;
+
+    if (rotator == 1) { // FhtKacRotator::rotate_into
+        for (uint32_t i = tid; i < D; i += kThreads) x[i] = i < dim ? qin[i] : 0.0f;
+        __syncthreads();
+        const uint32_t fo = D / 8;
+        if (trunc == D) {
+            for (int r = 0; r < 4; ++r) {
+                const uint8_t* f = rot_blob + r * fo;
+                for (uint32_t i = tid; i < D; i += kThreads)
+                    if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
+                __syncthreads();
+                fht_lds(x, D, tid);
+                for (uint32_t i = tid; i < D; i += kThreads) x[i] = x[i] * fac;
+                __syncthreads();
+            }
+        } else {
+            const uint32_t start = D - trunc, half = D / 2;
+            for (int r = 0; r < 4; ++r) {
+                const uint8_t* f = rot_blob + r * fo;
+                for (uint32_t i = tid; i < D; i += kThreads)
+                    if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
+                __syncthreads();
+                float* part = (r & 1) ? x + start : x;
+                fht_lds(part, trunc, tid);
+                for (uint32_t i = tid; i < trunc; i += kThreads) part[i] = part[i] * fac;
+                __syncthreads();
+                for (uint32_t i = tid; i < half; i += kThreads) {
+                    float a = x[i], b = x[i + half];
+                    x[i] = a + b;
+                    x[i + half] = a - b;
+                }
+                __syncthreads();
+            }
+            for (uint32_t i = tid; i < D; i += kThreads) x[i] = x[i] * 0.25f;
+            __syncthreads();
+        }
+    } else { // MatrixRotator::rotate_into: sequential unfused accumulate per output row
+        for (uint32_t i = tid; i < D; i += kThreads) y[i] = i < dim ? qin[i] : 0.0f;
+        __syncthreads();
+        const float* M = reinterpret_cast<const float*>(rot_blob);
+        for (uint32_t r = tid; r < D; r += kThreads) {
+            const float* row = M + (size_t)r * D;
+            float acc = 0.0f;
+            for (uint32_t c = 0; c < D; ++c) {
+                float p = y[c] * row[c];
+                acc = acc + p;
+            }
+            x[r] = acc;
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t i = tid; i < D; i += kThreads) rot_out[(size_t)q * D + i] = x[i];
+
+    // QueryPrecomputed::new — strictly sequential sums (Rust iter().sum() folds from -0.0)
+    if (tid == 0) {
+        float s = -0.0f;
+        for (uint32_t i = 0; i < D; ++i) s = s + x[i];
+        s_sum = s;
+        s_kmin = 0x7fffffff;
+        s_kmax = (int)0x80000000;
+    }
+    if (tid == 64) {
+        float n2 = -0.0f;
+        for (uint32_t i = 0; i < D; ++i) {
+            float p = x[i] * x[i];
+            n2 = n2 + p;
+        }
+        s_n2 = n2;
+    }
+    __syncthreads();
+
+    // pack_lut_f32 + QueryLut::new.  D <= 2048 -> at most 2 codebooks per thread.
+    const uint32_t ncb = D / 4;
+    float l[2][16];
+    int kmin = 0x7fffffff, kmax = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t c = tid + u * kThreads;
+        if (c < ncb) {
+            const float q0 = x[4 * c], q1 = x[4 * c + 1], q2 = x[4 * c + 2], q3 = x[4 * c + 3];
+            // lut[j] = lut[j - lowbit(j)] + q[KPOS[j]],  KPOS = {3,3,2,3,1,3,2,3,0,3,2,3,1,3,2,3}
+            l[u][0] = 0.0f;
+            l[u][1] = l[u][0] + q3;
+            l[u][2] = l[u][0] + q2;
+            l[u][3] = l[u][2] + q3;
+            l[u][4] = l[u][0] + q1;
+            l[u][5] = l[u][4] + q3;
+            l[u][6] = l[u][4] + q2;
+            l[u][7] = l[u][6] + q3;
+            l[u][8] = l[u][0] + q0;
+            l[u][9] = l[u][8] + q3;
+            l[u][10] = l[u][8] + q2;
+            l[u][11] = l[u][10] + q3;
+            l[u][12] = l[u][8] + q1;
+            l[u][13] = l[u][12] + q3;
+            l[u][14] = l[u][12] + q2;
+            l[u][15] = l[u][14] + q3;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int k = total_key(l[u][j]);
+                kmin = k < kmin ? k : kmin;
+                kmax = k > kmax ? k : kmax;
+            }
+        }
+    }
+    atomicMin(&s_kmin, kmin);
+    atomicMax(&s_kmax, kmax);
+    __syncthreads();
+    const float vl = key_to_float(s_kmin), vr = key_to_float(s_kmax);
+    const float delta = (vr - vl) / 255.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t c = tid + u * kThreads;
+        if (c < ncb) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (delta > 0.0f) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float v = roundf((l[u][j] - vl) / delta);
+                    v = v >= 0.0f ? v : 0.0f; // also maps NaN -> 0 like `as u8`
+                    v = v > 255.0f ? 255.0f : v;
+                    w[j >> 2] |= (uint32_t)v << (8 * (j & 3));
+                }
+            }
+            // device LUT order: adjacent codebooks swapped (position p holds codebook p^1) so that
+            // nibble m of a little-endian code dword indexes table (8*dword + m) directly.
+            uint4* dst = reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16);
+            *dst = make_uint4(w[0], w[1], w[2], w[3]);
+        } else if (c < Dc / 4) { // code-layout padding (D not a multiple of 64): all-zero tables
+            uint4* dst = reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16);
+            *dst = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (tid == 0) {
+        QueryConsts qc;
+        qc.delta = delta;
+        qc.sum_vl = vl * (float)(D / 4);
+        qc.sum_q = s_sum;
+        qc.qnorm = sqrtf(s_n2);
+        qc.k1x = -0.5f * s_sum;
+        const float cb = -((float)(1u << ex_bits) - 0.5f);
+        qc.kbx = cb * s_sum;
+        qc.scale = (float)(1u << ex_bits);
+        qc.pad = 0.0f;
+        consts[q] = qc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rank_scores: scores[q][c] = l2_distance_sqr(rot[q], cent[c]) or dot(...), in the reference's
+// AVX2 lane order: 8 strided accumulators, unfused mul/add, lanes summed 0..7, scalar tail.
+// Tile 32 queries x 32 centroids per workgroup, 2x2 pairs per thread, 32-dim LDS chunks.
+// ---------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(kThreads) void k_rank_scores(const float* __restrict__ rot, const float* __restrict__ cent,
+                                                          uint32_t nq, uint32_t nlist, uint32_t D,
+                                                          float* __restrict__ scores) {
+    __shared__ __align__(16) float Qs[32][36];
+    __shared__ __align__(16) float Cs[32][36];
+    const uint32_t tid = threadIdx.x, tq = tid >> 4, tc = tid & 15;
+    const uint32_t q0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const uint32_t Dmain = D & ~7u;
+    float acc[2][2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[a][b][l] = 0.0f;
+
+    const uint32_t lrow = tid >> 3, lcol = (tid & 7) * 4;
+    for (uint32_t k0 = 0; k0 < Dmain; k0 += 32) {
+        float4 qv = make_float4(0, 0, 0, 0), cv = make_float4(0, 0, 0, 0);
+        const uint32_t k = k0 + lcol;
+        if (q0 + lrow < nq) {
+            const float* p = rot + (size_t)(q0 + lrow) * D + k;
+            if (k + 4 <= Dmain && (D & 3) == 0) qv = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k < Dmain) qv.x = p[0];
+                if (k + 1 < Dmain) qv.y = p[1];
+                if (k + 2 < Dmain) qv.z = p[2];
+                if (k + 3 < Dmain) qv.w = p[3];
+            }
+        }
+        if (c0 + lrow < nlist) {
+            const float* p = cent + (size_t)(c0 + lrow) * D + k;
+            if (k + 4 <= Dmain && (D & 3) == 0) cv = *reinterpret_cast<const float4*>(p);
+            else {
+                if (k < Dmain) cv.x = p[0];
+                if (k + 1 < Dmain) cv.y = p[1];
+                if (k + 2 < Dmain) cv.z = p[2];
+                if (k + 3 < Dmain) cv.w = p[3];
+            }
+        }
+        *reinterpret_cast<float4*>(&Qs[lrow][lcol]) = qv;
+        *reinterpret_cast<float4*>(&Cs[lrow][lcol]) = cv;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float qa[2][8], cb[2][8];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float4 v0 = *reinterpret_cast<const float4*>(&Qs[2 * tq + a][8 * t]);
+                float4 v1 = *reinterpret_cast<const float4*>(&Qs[2 * tq + a][8 * t + 4]);
+                qa[a][0] = v0.x; qa[a][1] = v0.y; qa[a][2] = v0.z; qa[a][3] = v0.w;
+                qa[a][4] = v1.x; qa[a][5] = v1.y; qa[a][6] = v1.z; qa[a][7] = v1.w;
+                float4 w0 = *reinterpret_cast<const float4*>(&Cs[2 * tc + a][8 * t]);
+                float4 w1 = *reinterpret_cast<const float4*>(&Cs[2 * tc + a][8 * t + 4]);
+                cb[a][0] = w0.x; cb[a][1] = w0.y; cb[a][2] = w0.z; cb[a][3] = w0.w;
+                cb[a][4] = w1.x; cb[a][5] = w1.y; cb[a][6] = w1.z; cb[a][7] = w1.w;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) {
+                        float p;
+                        if (METRIC == 0) {
+                            float d = qa[a][l] - cb[b][l];
+                            p = d * d;
+                        } else {
+                            p = qa[a][l] * cb[b][l];
+                        }
+                        acc[a][b][l] = acc[a][b][l] + p;
+                    }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t qi = q0 + 2 * tq + a, ci = c0 + 2 * tc + b;
+            if (qi < nq && ci < nlist) {
+                float sum = 0.0f;
+                if (Dmain > 0) {
+                    sum = -0.0f;
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) sum = sum + acc[a][b][l];
+                }
+                for (uint32_t i = Dmain; i < D; ++i) { // scalar tail
+                    float x = rot[(size_t)qi * D + i], y = cent[(size_t)ci * D + i], p;
+                    if (METRIC == 0) {
+                        float d = x - y;
+                        p = d * d;
+                    } else {
+                        p = x * y;
+                    }
+                    sum = sum + p;
+                }
+                scores[(size_t)qi * nlist + ci] = sum;
+            }
+        }
+}
+
+// canonical single-pair reductions used for the second per-probe quantity
+__device__ inline float canon_l2(const float* a, const float* __restrict__ b, uint32_t D) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t Dmain = D & ~7u;
+    for (uint32_t i = 0; i < Dmain; i += 8)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float d = a[i + l] - b[i + l];
+            float p = d * d;
+            acc[l] = acc[l] + p;
+        }
+    float sum = 0.0f;
+    if (Dmain) {
+        sum = -0.0f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) sum = sum + acc[l];
+    }
+    for (uint32_t i = Dmain; i < D; ++i) {
+        float d = a[i] - b[i];
+        float p = d * d;
+        sum = sum + p;
+    }
+    return sum;
+}
+__device__ inline float canon_dot(const float* a, const float* __restrict__ b, uint32_t D) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t Dmain = D & ~7u;
+    for (uint32_t i = 0; i < Dmain; i += 8)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            float p = a[i + l] * b[i + l];
+            acc[l] = acc[l] + p;
+        }
+    float sum = 0.0f;
+    if (Dmain) {
+        sum = -0.0f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) sum = sum + acc[l];
+    }
+    for (uint32_t i = Dmain; i < D; ++i) {
+        float p = a[i] * b[i];
+        sum = sum + p;
+    }
+    return sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_select: one workgroup per query.  64-bit key = (ordered score << 32) | cid, ascending;
+// radix-select the nprobe-th key, collect, bitonic-sort; then per-probe constants and work list.
+// dynamic LDS: sel[np2] u64 | qrot[D] f32 | part[kThreads] u32
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t cid, int metric) {
+    int32_t k = total_key(score);
+    if (metric == 1) k = ~k; // descending score
+    return ((uint64_t)((uint32_t)k ^ 0x80000000u) << 32) | cid;
+}
+
+__global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ scores, uint32_t nlist, uint32_t nprobe,
+                                                     uint32_t np2, int metric, const float* __restrict__ rot,
+                                                     const float* __restrict__ cent, uint32_t D,
+                                                     const uint32_t* __restrict__ list_gb0,
+                                                     const uint32_t* __restrict__ list_n,
+                                                     ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
+                                                     uint64_t wl_stride, uint32_t* __restrict__ nstream,
+                                                     unsigned long long* __restrict__ nvec_probed) {
+    extern __shared__ __align__(16) unsigned char smraw[];
+    uint64_t* sel = reinterpret_cast<uint64_t*>(smraw);
+    float* qrot = reinterpret_cast<float*>(smraw + (size_t)np2 * 8);
+    uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
+    __shared__ uint32_t hist[256];
+    __shared__ uint64_t s_prefix, s_mask;
+    __shared__ uint32_t s_k, s_cnt;
+    __shared__ unsigned long long s_nvec;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const float* sc = scores + (size_t)q * nlist;
+
+    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
+    if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; }
+    __syncthreads();
+
+    if (nprobe < nlist) {
+        for (int pass = 7; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            hist[tid] = 0;
+            __syncthreads();
+            const uint64_t prefix = s_prefix, mask = s_mask;
+            for (uint32_t i = tid; i < nlist; i += kThreads) {
+                uint64_t key = make_key(sc[i], i, metric);
+                if ((key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t k = s_k, cum = 0, b = 0;
+                for (; b < 256; ++b) {
+                    uint32_t h = hist[b];
+                    if (k < cum + h) break;
+                    cum += h;
+                }
+                s_k = k - cum;
+                s_prefix = prefix | ((uint64_t)b << shift);
+                s_mask = mask | (0xffull << shift);
+            }
+            __syncthreads();
+        }
+    } else if (tid == 0) {
+        s_prefix = ~0ull;
+    }
+    __syncthreads();
+    const uint64_t kstar = s_prefix;
+    for (uint32_t i = tid; i < np2; i += kThreads) sel[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t i = tid; i < nlist; i += kThreads) {
+        uint64_t key = make_key(sc[i], i, metric);
+        if (key <= kstar) {
+            uint32_t pos = atomicAdd(&s_cnt, 1u);
+            if (pos < np2) sel[pos] = key;
+        }
+    }
+    __syncthreads();
+    // bitonic sort ascending
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < np2; i += kThreads) {
+                uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    uint64_t a = sel[i], b = sel[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { sel[i] = b; sel[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+
+    // per-probe constants (src/ivf.rs:1850-1857) + block counts
+    const uint32_t per = (nprobe + kThreads - 1) / kThreads;
+    const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
+    uint32_t local = 0;
+    unsigned long long local_vec = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        uint32_t cid = (uint32_t)(sel[r] & 0xffffffffu);
+        float s = sc[cid], dist, dot;
+        const float* c = cent + (size_t)cid * D;
+        if (metric == 0) { dist = s; dot = canon_dot(qrot, c, D); }
+        else { dot = s; dist = canon_l2(qrot, c, D); }
+        ProbeInfo pi;
+        pi.g_add = metric == 0 ? dist : -dot;
+        pi.g_err = sqrtf(dist);
+        pi.dotqc = dot;
+        pi.cid = cid;
+        probe[(size_t)q * nprobe + r] = pi;
+        local += (list_n[cid] + 31u) >> 5;
+        local_vec += list_n[cid];
+    }
+    part[tid] = local;
+    if (local_vec) atomicAdd(&s_nvec, local_vec);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < kThreads; ++i) { uint32_t v = part[i]; part[i] = run; run += v; }
+        nstream[q] = run;
+        nvec_probed[q] = s_nvec; // sum of n_c over the probed lists: the scan's algorithmic work
+    }
+    __syncthreads();
+    uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    for (uint32_t r = r0; r < r1; ++r) {
+        uint32_t cid = (uint32_t)(sel[r] & 0xffffffffu);
+        uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
+        for (uint32_t b = 0; b < nb; ++b) {
+            uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
+            WorkItem wi;
+            wi.gblock = gb + b;
+            wi.rank_nvalid = (r << 6) | nv;
+            wl[pos++] = wi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan
+// ---------------------------------------------------------------------------------------------
+struct ScanParams {
+    const uint8_t* blocks;   // [n_blocks][4Dc + 384]: lane-major sign codes | f_add[32] | f_rescale[32] | f_error[32]
+    const uint64_t* ids;     // [n_blocks*32]
+    const uint8_t* ex_codes; // [n_blocks*32][D*ex/8]   (reference packed layout per vector)
+    const float* f_add_ex;   // [n_blocks*32]
+    const float* f_rescale_ex;
+    const uint8_t* lut;      // [nq][4Dc] (pair-swapped codebook order); Dc = D rounded up to x64
+    const float* rot;        // [nq][D]
+    const QueryConsts* consts;
+    const ProbeInfo* probe;  // [nq][nprobe]
+    const WorkItem* wl;      // [nq][wl_stride]
+    const uint32_t* nstream; // [nq]
+    const uint32_t* filter;  // dense bitset or null
+    uint64_t filter_nbits;
+    uint64_t wl_stride;
+    uint64_t* out_ids;
+    float* out_scores;
+    uint32_t* out_counts;
+    unsigned long long* diag; // [nq][3] or null
+    uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
+};
+
+constexpr int kTileBlocks = 8;              // 32-vector blocks per tile (1 per half-wave)
+constexpr int kTileCand = kTileBlocks * 32; // 512 candidates
+
+// 8 nibble lookups of one little-endian code dword; table p+16*m serves nibble m.
+// The empty asm pins the running sum so the integer adds are not re-associated into one big
+// end-of-block reduction (which made hipcc spill every ds_read result to scratch).
+__device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, const uint8_t* p) {
+    uint32_t s = p[x & 15u];
+    s += p[16 + ((x >> 4) & 15u)];
+    s += p[32 + ((x >> 8) & 15u)];
+    s += p[48 + ((x >> 12) & 15u)];
+    s += p[64 + ((x >> 16) & 15u)];
+    s += p[80 + ((x >> 20) & 15u)];
+    s += p[96 + ((x >> 24) & 15u)];
+    s += p[112 + (x >> 28)];
+    acc += s;
+    asm volatile("" : "+v"(acc));
+}
+
+// Sum over all Dc/4 codebooks of lut[codebook][nibble] for one vector (lane l32 of a block).
+template <int DT>
+__device__ __forceinline__ uint32_t accumulate_block(const uint8_t* __restrict__ blk, const uint8_t* lut,
+                                                     uint32_t l32, uint32_t Drt) {
+    const uint32_t D = DT ? (uint32_t)DT : Drt;
+    const uint32_t G16 = D >> 7;
+    const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
+    uint32_t acc = 0;
+    if (DT) {
+        uint4 x[(DT >> 7) ? (DT >> 7) : 1];
+#pragma unroll
+        for (uint32_t g = 0; g < (DT >> 7); ++g) x[g] = cp[g * 32]; // all code granules in flight first
+#pragma unroll
+        for (uint32_t g = 0; g < (DT >> 7); ++g) {
+            look8(acc, x[g].x, lut + g * 512);
+            look8(acc, x[g].y, lut + g * 512 + 128);
+            look8(acc, x[g].z, lut + g * 512 + 256);
+            look8(acc, x[g].w, lut + g * 512 + 384);
+        }
+    } else {
+        for (uint32_t g = 0; g < G16; ++g) {
+            uint4 x = cp[g * 32];
+            look8(acc, x.x, lut + g * 512);
+            look8(acc, x.y, lut + g * 512 + 128);
+            look8(acc, x.z, lut + g * 512 + 256);
+            look8(acc, x.w, lut + g * 512 + 384);
+        }
+    }
+    if (D & 64u) {
+        const uint2* tp = reinterpret_cast<const uint2*>(blk + G16 * 512) + l32;
+        uint2 y = *tp;
+        look8(acc, y.x, lut + G16 * 512);
+        look8(acc, y.y, lut + G16 * 512 + 128);
+    }
+    return acc;
+}
+
+// LDS carve-up of k_scan (dynamic): lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 |
+// q_slot,q_lb,q_ip,q_gadd,q_d [kTileCand] | cnt[kTileBlocks]
+template <int DT>
+__global__ __launch_bounds__(kThreads, 4) void k_scan(ScanParams P) {
+    extern __shared__ __align__(16) unsigned char smraw[];
+    const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
+    const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
+    uint8_t* s_lut = smraw;
+    float* s_q = reinterpret_cast<float*>(smraw + (size_t)Dc * 4);
+    float* heap_d = s_q + D;
+    uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
+    uint32_t* q_slot = heap_s + (P.top_k + 1);
+    float* q_lb = reinterpret_cast<float*>(q_slot + kTileCand);
+    float* q_ip = q_lb + kTileCand;
+    float* q_gadd = q_ip + kTileCand;
+    float* q_d = q_gadd + kTileCand;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(q_d + kTileCand);
+    // no static __shared__ in this kernel: the dynamic region must start at LDS address 0 so that the
+    // LUT offsets fold into the ds_read_u8 immediate (saves one VALU add per lookup)
+    float& s_T = *reinterpret_cast<float*>(s_cnt + kTileBlocks);
+    uint32_t& s_len = *(s_cnt + kTileBlocks + 1);
+    uint32_t* s_nskip = s_cnt + kTileBlocks + 2;
+
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, half = lane >> 5, l32 = lane & 31u, hw = tid >> 5; // hw: half-wave 0..7
+    const uint32_t top_k = P.top_k, ex_bits = P.ex_bits;
+    const size_t stride = (size_t)Dc * 4 + 384;
+
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
+        uint4* dst = reinterpret_cast<uint4*>(s_lut);
+        for (uint32_t i = tid; i < Dc / 4; i += kThreads) dst[i] = src[i];
+        for (uint32_t i = tid; i < D; i += kThreads) s_q[i] = P.rot[(size_t)q * D + i];
+        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; }
+    }
+    const QueryConsts qc = P.consts[q];
+    const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
+    const WorkItem* wl = P.wl + (size_t)q * P.wl_stride;
+    const uint32_t ns = P.nstream[q];
+    __syncthreads();
+
+    uint32_t heap_len = 0;                    // thread 0 only
+    uint32_t n_skip = 0, n_ext = 0, n_est = 0; // diag (n_skip: every thread; others thread 0)
+    const uint32_t exb = D * ex_bits / 8;
+
+    for (uint32_t t0 = 0; t0 < ns; t0 += kTileBlocks) {
+        const float T = s_T;
+        const uint32_t s = t0 + hw;
+        bool surv = false;
+        uint32_t slot = 0;
+        float v_lb = 0.0f, v_ip = 0.0f, v_est = 0.0f, v_gadd = 0.0f;
+        if (s < ns) {
+            const WorkItem wi = wl[s];
+            const uint32_t rank = wi.rank_nvalid >> 6, nvalid = wi.rank_nvalid & 63u;
+            const uint8_t* blk = P.blocks + (size_t)wi.gblock * stride;
+            const uint32_t accu = accumulate_block<DT>(blk, s_lut, l32, Dc) & 0xffffu;
+            const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
+            const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
+            const ProbeInfo pi = probe[rank];
+            // compute_batch_distances_u16 (AVX2 body): only the first op is fused
+            const float ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
+            const float tt = ip + qc.k1x;
+            const float rs = f_rescale * tt;
+            float est = f_add + pi.g_add;
+            est = est + rs;
+            const float er = f_error * pi.g_err;
+            float lb = est - er;
+            slot = wi.gblock * 32u + l32;
+            bool valid = l32 < nvalid;
+            if (valid && P.filter) {
+                const uint32_t id32 = (uint32_t)P.ids[slot];
+                valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
+            }
+            if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(pi.dotqc + qc.qnorm);
+            surv = valid && (lb < T);
+            if (valid && !surv) ++n_skip;
+            v_lb = lb; v_ip = ip; v_est = est; v_gadd = pi.g_add;
+        }
+        const unsigned long long bal = __ballot(surv);
+        const uint32_t mask32 = (uint32_t)(bal >> (half * 32));
+        if (l32 == 0) s_cnt[hw] = __popc(mask32);
+        __syncthreads();
+        uint32_t S = 0, base = 0;
+        for (uint32_t j = 0; j < (uint32_t)kTileBlocks; ++j) {
+            const uint32_t c = s_cnt[j];
+            base += j < hw ? c : 0u;
+            S += c;
+        }
+        if (surv) {
+            const uint32_t pos = base + __popc(mask32 & ((1u << l32) - 1u));
+            q_slot[pos] = slot;
+            q_lb[pos] = v_lb;
+            q_ip[pos] = v_ip;
+            q_gadd[pos] = v_gadd;
+            q_d[pos] = v_est;
+        }
+        if (S == 0) { __syncthreads(); continue; } // uniform
+        __syncthreads();
+
+        if (ex_bits) { // ex-code refine: 16 lanes per survivor, AVX-512 lane order + halving tree
+            const uint32_t gl = tid & 15u, grp = tid >> 4;
+            const uint32_t sh_hi = 8u * (gl & 3u) + 2u * (gl >> 2);
+            const uint32_t sh_lo = 8u * (gl & 3u) + 4u * (gl >> 3);
+            const bool hi_dw = ((gl & 7u) >> 2) != 0;
+            for (uint32_t i = grp; i < S; i += 16) {
+                const uint32_t sl = q_slot[i];
+                const uint32_t* ex = reinterpret_cast<const uint32_t*>(P.ex_codes + (size_t)sl * exb);
+                float sacc = 0.0f;
+                if (ex_bits == 6) {
+#pragma unroll 4
+                    for (uint32_t t = 0; t < D / 16; ++t) {
+                        const uint32_t lo0 = ex[3 * t], lo1 = ex[3 * t + 1], hi = ex[3 * t + 2];
+                        const uint32_t lo = hi_dw ? lo1 : lo0;
+                        const uint32_t code = ((lo >> sh_lo) & 15u) | (((hi >> sh_hi) & 3u) << 4);
+                        sacc = fmaf((float)code, s_q[16 * t + gl], sacc);
+                    }
+                } else {
+#pragma unroll 4
+                    for (uint32_t t = 0; t < D / 16; ++t) {
+                        const uint32_t code = (ex[t] >> sh_hi) & 3u;
+                        sacc = fmaf((float)code, s_q[16 * t + gl], sacc);
+                    }
+                }
+                sacc = sacc + __shfl_xor(sacc, 8, 16);
+                sacc = sacc + __shfl_xor(sacc, 4, 16);
+                sacc = sacc + __shfl_xor(sacc, 2, 16);
+                sacc = sacc + __shfl_xor(sacc, 1, 16);
+                if (gl == 0) {
+                    float tt = qc.scale * q_ip[i];
+                    tt = tt + sacc;
+                    tt = tt + qc.kbx;
+                    const float a = P.f_add_ex[sl] + q_gadd[i];
+                    const float m = P.f_rescale_ex[sl] * tt;
+                    q_d[i] = a + m;
+                }
+            }
+            __syncthreads();
+        }
+
+        if (tid == 0) { // exact sequential replay of the reference's prune/push/pop loop
+            for (uint32_t i = 0; i < S; ++i) {
+                const float lb = q_lb[i];
+                const float distk = heap_len < top_k ? INFINITY : heap_d[0];
+                if (lb >= distk) { ++n_skip; continue; }
+                ++n_ext;
+                const float d = q_d[i];
+                if (!finite_f(d)) continue;
+                ++n_est;
+                const uint32_t sl = q_slot[i];
+                // BinaryHeap::push -> sift_up(0, old_len)
+                uint32_t pos = heap_len++;
+                const int kd = total_key(d);
+                while (pos > 0) {
+                    const uint32_t parent = (pos - 1) >> 1;
+                    if (kd <= total_key(heap_d[parent])) break;
+                    heap_d[pos] = heap_d[parent];
+                    heap_s[pos] = heap_s[parent];
+                    pos = parent;
+                }
+                heap_d[pos] = d;
+                heap_s[pos] = sl;
+                if (heap_len > top_k) { // BinaryHeap::pop: last -> root, sift_down_to_bottom, sift_up
+                    --heap_len;
+                    if (heap_len > 0) {
+                        const float ed = heap_d[heap_len];
+                        const uint32_t es = heap_s[heap_len];
+                        const uint32_t end = heap_len;
+                        uint32_t p = 0, child = 1;
+                        while (end >= 2 && child <= end - 2) {
+                            child += (total_key(heap_d[child]) <= total_key(heap_d[child + 1])) ? 1u : 0u;
+                            heap_d[p] = heap_d[child];
+                            heap_s[p] = heap_s[child];
+                            p = child;
+                            child = 2 * p + 1;
+                        }
+                        if (child == end - 1) {
+                            heap_d[p] = heap_d[child];
+                            heap_s[p] = heap_s[child];
+                            p = child;
+                        }
+                        const int ke = total_key(ed);
+                        while (p > 0) {
+                            const uint32_t parent = (p - 1) >> 1;
+                            if (ke <= total_key(heap_d[parent])) break;
+                            heap_d[p] = heap_d[parent];
+                            heap_s[p] = heap_s[parent];
+                            p = parent;
+                        }
+                        heap_d[p] = ed;
+                        heap_s[p] = es;
+                    }
+                }
+            }
+            s_T = heap_len < top_k ? INFINITY : heap_d[0];
+        }
+        __syncthreads();
+    }
+
+    // into_sorted_vec (src/ivf.rs:1874-1878) on thread 0, then parallel write-out
+    if (tid == 0) {
+        uint32_t end = heap_len;
+        while (end > 1) {
+            --end;
+            float td = heap_d[0]; heap_d[0] = heap_d[end]; heap_d[end] = td;
+            uint32_t ts = heap_s[0]; heap_s[0] = heap_s[end]; heap_s[end] = ts;
+            // sift_down_range(0, end)
+            const float ed = heap_d[0];
+            const uint32_t es = heap_s[0];
+            const int ke = total_key(ed);
+            uint32_t p = 0, child = 1;
+            bool placed = false;
+            while (end >= 2 && child <= end - 2) {
+                child += (total_key(heap_d[child]) <= total_key(heap_d[child + 1])) ? 1u : 0u;
+                if (ke >= total_key(heap_d[child])) { placed = true; break; }
+                heap_d[p] = heap_d[child];
+                heap_s[p] = heap_s[child];
+                p = child;
+                child = 2 * p + 1;
+            }
+            if (!placed && child == end - 1 && ke < total_key(heap_d[child])) {
+                heap_d[p] = heap_d[child];
+                heap_s[p] = heap_s[child];
+                p = child;
+            }
+            heap_d[p] = ed;
+            heap_s[p] = es;
+        }
+        s_len = heap_len;
+    }
+    if (P.diag && n_skip) atomicAdd(s_nskip, n_skip);
+    __syncthreads();
+    const uint32_t len = s_len;
+    for (uint32_t i = tid; i < top_k; i += kThreads) {
+        uint64_t id = ~0ull;
+        float sc = __int_as_float(0x7fc00000);
+        if (i < len) {
+            id = P.ids[heap_s[i]];
+            sc = P.metric == 0 ? heap_d[i] : -heap_d[i];
+        }
+        P.out_ids[(size_t)q * top_k + i] = id;
+        P.out_scores[(size_t)q * top_k + i] = sc;
+    }
+    if (tid == 0) {
+        P.out_counts[q] = len;
+        if (P.diag) {
+            P.diag[(size_t)q * 3 + 0] = n_est;
+            P.diag[(size_t)q * 3 + 1] = *s_nskip;
+            P.diag[(size_t)q * 3 + 2] = ex_bits ? n_ext : 0;
+        }
+    }
+}
+
+} // namespace rbq

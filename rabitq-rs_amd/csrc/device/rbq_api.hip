@@ -1,0 +1,650 @@
+// rbq_api.hip — C ABI (include/rbq.h) over the HIP kernels of kernels.hpp.  gfx950 only.
+//
+// Host responsibilities: validate like the reference (src/ivf.rs:1754-1769,1484-1702), re-lay the
+// reference's ClusterData bytes into the device layout (one-time, at create/load), own HBM, and
+// enqueue prep -> rank -> select -> scan for each query batch.  There is no CPU compute path:
+// every failure to reach the GPU surfaces as RBQ_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rbq.h"
+#include "kernels.hpp"
+
+using namespace rbq;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& detail) {
+    g_err = detail;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            return fail(RBQ_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+uint32_t floor_log2_u32(uint32_t x) { uint32_t r = 0; while (x >>= 1) ++r; return r; }
+uint32_t next_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return RBQ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return RBQ_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace {
+    hipStream_t stream = nullptr;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_ids, out_scores, out_counts, diag, filter;
+    void release() {
+        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &out_ids, &out_scores,
+                          &out_counts, &diag, &filter})
+            b->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+struct StageProf {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double ms = 0;
+    uint64_t launches = 0;
+};
+
+} // namespace
+
+struct rbq_index {
+    int device = 0;
+    uint32_t dim = 0, D = 0, Dc = 0;
+    uint8_t metric = 0, rotator = 0, ex_bits = 0;
+    uint64_t n_vectors = 0, n_lists = 0, n_blocks = 0;
+    uint32_t trunc = 0;
+    float fac = 1.0f;
+    // device arrays
+    void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
+         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr;
+    // host
+    std::vector<uint32_t> h_list_n;
+    std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
+    std::mutex mu;
+    std::vector<Workspace*> pool;
+    // profiling
+    bool profiling = false;
+    StageProf prof[3]; // prep, rank(+select), scan
+    uint64_t prof_scan_bytes = 0;
+    std::vector<std::pair<void*, uint64_t>> prof_pending_nstream; // unused placeholder
+};
+
+namespace {
+
+void free_index(rbq_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    for (void* p : {ix->d_rot_blob, ix->d_centroids, ix->d_blocks, ix->d_ids, ix->d_ex, ix->d_fadd_ex, ix->d_fres_ex,
+                    ix->d_list_gb0, ix->d_list_n})
+        if (p) (void)hipFree(p);
+    for (Workspace* w : ix->pool) { w->release(); delete w; }
+    for (auto& sp : ix->prof)
+        for (auto& e : sp.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete ix;
+}
+
+// inverse of pack_codes (src/simd.rs:864-904): KPERM0[j] = (j>>1) + 8*(j&1)  =>  j = 2*(u&7) + (u>>3)
+inline uint8_t fastscan_byte(const uint8_t* packed, size_t col, uint32_t v) {
+    const uint32_t u = v & 15u, j = 2u * (u & 7u) + (u >> 3);
+    const uint8_t a = packed[col * 32 + j], b = packed[col * 32 + 16 + j];
+    const uint8_t hi = v < 16 ? (a & 15) : (a >> 4);
+    const uint8_t lo = v < 16 ? (b & 15) : (b >> 4);
+    return (uint8_t)((hi << 4) | lo);
+}
+
+// One reference batch record -> one device block: lane-major code granules + the three factor rows.
+void relayout_block(const uint8_t* rec, uint32_t D, uint32_t Dc, uint8_t* dst) {
+    const size_t dim_bytes = D / 8, G16 = Dc >> 7;
+    std::memset(dst, 0, (size_t)Dc * 4);
+    for (uint32_t v = 0; v < 32; ++v)
+        for (size_t col = 0; col < dim_bytes; ++col) {
+            const uint8_t b = fastscan_byte(rec, col, v);
+            const size_t g = col >> 4;
+            if (g < G16) dst[g * 512 + v * 16 + (col & 15)] = b;
+            else dst[G16 * 512 + v * 8 + (col & 7)] = b;
+        }
+    std::memcpy(dst + (size_t)Dc * 4, rec + (size_t)D * 4, 384);
+}
+
+int validate_header(const rbq_header* h) {
+    if (!h) return fail(RBQ_INVALID_CONFIG, "null header");
+    if (h->dim == 0) return fail(RBQ_INVALID_CONFIG, "dimension must be positive");
+    if (h->padded_dim < h->dim) return fail(RBQ_INVALID_CONFIG, "padded_dim must be >= dim");
+    if (h->metric > 1) return fail(RBQ_INVALID_CONFIG, "unknown metric tag");
+    if (h->rotator > 1) return fail(RBQ_INVALID_CONFIG, "unknown rotator type tag");
+    if (h->ex_bits != 0 && h->ex_bits != 2 && h->ex_bits != 6)
+        return fail(RBQ_INVALID_CONFIG, "Unsupported ex_bits: only 0 (1-bit total), 2 (3-bit total), and 6 (7-bit total) are supported");
+    if (h->padded_dim % 16 != 0) return fail(RBQ_INVALID_CONFIG, "Dimension must be multiple of 16 for SIMD");
+    if (h->padded_dim > 2048)
+        return fail(RBQ_INVALID_CONFIG, "padded_dim > 2048 (high-accuracy i32 LUT mode) is not supported");
+    if (h->rotator == RBQ_ROTATOR_FHT_KAC) {
+        if (h->padded_dim % 64 != 0) return fail(RBQ_INVALID_CONFIG, "FHT rotator requires dimension to be multiple of 64");
+        if (h->rotator_len != (uint64_t)4 * h->padded_dim / 8) return fail(RBQ_INVALID_PERSISTENCE, "FHT rotator flip bits length mismatch");
+    } else {
+        if (h->rotator_len != (uint64_t)h->padded_dim * h->padded_dim * 4) return fail(RBQ_INVALID_PERSISTENCE, "rotator matrix length mismatch");
+    }
+    if (h->n_lists == 0) return fail(RBQ_INVALID_CONFIG, "nlist must be positive");
+    if (h->n_lists > 0xffffffffull) return fail(RBQ_INVALID_CONFIG, "too many lists");
+    return RBQ_OK;
+}
+
+template <typename T>
+int upload(void** dptr, const std::vector<T>& v) {
+    size_t bytes = v.size() * sizeof(T);
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice));
+    return RBQ_OK;
+}
+
+int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices, const int* devices, rbq_index** out) {
+    if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
+    *out = nullptr;
+    int rc = validate_header(hdr);
+    if (rc) return rc;
+    if (n_devices != 1) return fail(RBQ_INVALID_CONFIG, "n_devices must be 1 (one handle per GPU; shard queries across handles)");
+    if (!lists) return fail(RBQ_INVALID_CONFIG, "null lists");
+
+    int dev = 0;
+    if (devices) dev = devices[0];
+    else HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipSetDevice(dev));
+
+    rbq_index* ix = new rbq_index();
+    ix->device = dev;
+    ix->dim = hdr->dim; ix->D = hdr->padded_dim; ix->Dc = (hdr->padded_dim + 63u) / 64u * 64u;
+    ix->metric = hdr->metric; ix->rotator = hdr->rotator; ix->ex_bits = hdr->ex_bits;
+    ix->n_lists = hdr->n_lists;
+    ix->trunc = 1u << floor_log2_u32(hdr->dim);
+    ix->fac = 1.0f / std::sqrt((float)ix->trunc);
+
+    const uint32_t D = ix->D, Dc = ix->Dc;
+    const size_t ref_stride = (size_t)D * 4 + 384, dev_stride = (size_t)Dc * 4 + 384, exb = (size_t)D * ix->ex_bits / 8;
+    std::vector<uint32_t> gb0(ix->n_lists), ln(ix->n_lists);
+    uint64_t nblocks = 0, nvec = 0;
+    for (uint64_t c = 0; c < ix->n_lists; ++c) {
+        const rbq_list_view& L = lists[c];
+        if (L.n > 0xffffffffull) { free_index(ix); return fail(RBQ_INVALID_CONFIG, "list too large"); }
+        const uint64_t nb = (L.n + 31) / 32;
+        if (L.batch_len != nb * ref_stride) { free_index(ix); return fail(RBQ_INVALID_PERSISTENCE, "batch_data length mismatch - possible corruption or version incompatibility"); }
+        if (L.n && (!L.centroid || !L.ids || !L.batch_data || (ix->ex_bits && (!L.ex_codes || !L.f_add_ex || !L.f_rescale_ex)))) {
+            free_index(ix); return fail(RBQ_INVALID_CONFIG, "null list array");
+        }
+        if (!L.centroid) { free_index(ix); return fail(RBQ_INVALID_CONFIG, "null centroid"); }
+        gb0[c] = (uint32_t)nblocks; ln[c] = (uint32_t)L.n;
+        nblocks += nb; nvec += L.n;
+    }
+    if (nblocks * 32 > 0xffffffffull) { free_index(ix); return fail(RBQ_INVALID_CONFIG, "index too large for 32-bit vector slots"); }
+    ix->n_blocks = nblocks; ix->n_vectors = nvec; ix->h_list_n = ln;
+
+    // host staging in device layout
+    std::vector<float> cent((size_t)ix->n_lists * D);
+    std::vector<uint8_t> blocks(nblocks * dev_stride);
+    std::vector<uint64_t> ids(nblocks * 32, ~0ull);
+    std::vector<uint8_t> ex(exb ? nblocks * 32 * exb : 0);
+    std::vector<float> fa(ix->ex_bits ? nblocks * 32 : 0), fr(ix->ex_bits ? nblocks * 32 : 0);
+    for (uint64_t c = 0; c < ix->n_lists; ++c) {
+        const rbq_list_view& L = lists[c];
+        std::memcpy(&cent[c * D], L.centroid, sizeof(float) * D);
+        const uint64_t nb = (L.n + 31) / 32;
+        for (uint64_t b = 0; b < nb; ++b)
+            relayout_block(L.batch_data + b * ref_stride, D, Dc, &blocks[(gb0[c] + b) * dev_stride]);
+        const size_t s0 = (size_t)gb0[c] * 32;
+        if (L.n) {
+            std::memcpy(&ids[s0], L.ids, L.n * 8);
+            if (ix->ex_bits) {
+                std::memcpy(&ex[s0 * exb], L.ex_codes, L.n * exb);
+                std::memcpy(&fa[s0], L.f_add_ex, L.n * 4);
+                std::memcpy(&fr[s0], L.f_rescale_ex, L.n * 4);
+            }
+        }
+    }
+    std::vector<uint8_t> blob(hdr->rotator_blob, hdr->rotator_blob + hdr->rotator_len);
+    std::vector<uint64_t> nblk(ix->n_lists);
+    for (uint64_t c = 0; c < ix->n_lists; ++c) nblk[c] = (ln[c] + 31u) / 32u;
+    std::sort(nblk.begin(), nblk.end(), std::greater<uint64_t>());
+    ix->nblk_desc_prefix.assign(ix->n_lists + 1, 0);
+    for (uint64_t c = 0; c < ix->n_lists; ++c) ix->nblk_desc_prefix[c + 1] = ix->nblk_desc_prefix[c] + nblk[c];
+
+#define UP(dst, vec)                                             \
+    do {                                                         \
+        int _rc = upload(&ix->dst, vec);                         \
+        if (_rc) { free_index(ix); return _rc; }                 \
+    } while (0)
+    UP(d_rot_blob, blob); UP(d_centroids, cent); UP(d_blocks, blocks); UP(d_ids, ids); UP(d_ex, ex);
+    UP(d_fadd_ex, fa); UP(d_fres_ex, fr); UP(d_list_gb0, gb0); UP(d_list_n, ln);
+#undef UP
+    *out = ix;
+    return RBQ_OK;
+}
+
+Workspace* take_ws(rbq_index* ix) {
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        if (!ix->pool.empty()) { Workspace* w = ix->pool.back(); ix->pool.pop_back(); return w; }
+    }
+    Workspace* w = new Workspace();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    return w;
+}
+void give_ws(rbq_index* ix, Workspace* w) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->pool.push_back(w);
+}
+
+struct ProfScope {
+    rbq_index* ix; int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(rbq_index* ix_, int st, hipStream_t s_) : ix(ix_), stage(st), s(s_) {
+        if (ix->profiling) {
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (ix->profiling && a) {
+            (void)hipEventRecord(b, s);
+            std::lock_guard<std::mutex> g(ix->mu);
+            ix->prof[stage].ev.emplace_back(a, b);
+        }
+    }
+};
+
+template <int DT>
+hipError_t launch_scan(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scan<DT>, dim3(nq), dim3(kThreads), lds, s, P);
+    return hipGetLastError();
+}
+
+// Core: everything on device pointers, enqueued on `stream`. Workspace buffers come from `w`.
+int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t nq, uint32_t top_k, uint32_t nprobe_in,
+                  const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
+                  rbq_diag* d_diag, hipStream_t stream) {
+    const uint32_t D = ix->D, Dc = ix->Dc;
+    const uint32_t nlist = (uint32_t)ix->n_lists;
+    uint32_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
+    if (nprobe > nlist) nprobe = nlist;
+    if (nprobe > 4096) return fail(RBQ_INVALID_CONFIG, "nprobe > 4096 is not supported by the GPU probe selector");
+    if (top_k > 4096) return fail(RBQ_INVALID_CONFIG, "top_k > 4096 is not supported by the GPU top-k stage");
+    const uint32_t np2 = next_pow2(nprobe);
+    const uint64_t wl_stride = std::max<uint64_t>(ix->nblk_desc_prefix[nprobe], 1);
+
+    int rc;
+    if ((rc = w->rot.ensure(nq * D * 4))) return rc;
+    if ((rc = w->lut.ensure(nq * (size_t)Dc * 4))) return rc;
+    if ((rc = w->consts.ensure(nq * sizeof(QueryConsts)))) return rc;
+    if ((rc = w->scores.ensure(nq * (size_t)nlist * 4))) return rc;
+    if ((rc = w->probe.ensure(nq * (size_t)nprobe * sizeof(ProbeInfo)))) return rc;
+    if ((rc = w->wl.ensure(nq * wl_stride * sizeof(WorkItem)))) return rc;
+    if ((rc = w->nstream.ensure(nq * 4))) return rc;
+    if ((rc = w->nvec.ensure(nq * 8))) return rc;
+
+    {
+        ProfScope ps(ix, 0, stream);
+        const size_t lds = (size_t)D * 4 * 2;
+        hipLaunchKernelGGL(k_prep, dim3((uint32_t)nq), dim3(kThreads), lds, stream, d_queries, ix->dim, D, Dc, (int)ix->rotator,
+                           (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p,
+                           (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(ix, 1, stream);
+        dim3 grid((nlist + 31) / 32, (uint32_t)((nq + 31) / 32));
+        if (ix->metric == 0)
+            hipLaunchKernelGGL(k_rank_scores<0>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
+                               (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
+        else
+            hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
+                               (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
+        HIP_TRY(hipGetLastError());
+        const size_t lds = (size_t)np2 * 8 + (size_t)D * 4 + kThreads * 4;
+        hipLaunchKernelGGL(k_select, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (const float*)w->scores.p, nlist, nprobe,
+                           np2, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
+                           (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
+                           (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p);
+        HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(ix, 2, stream);
+        ScanParams P;
+        P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
+        P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
+        P.lut = (const uint8_t*)w->lut.p; P.rot = (const float*)w->rot.p; P.consts = (const QueryConsts*)w->consts.p;
+        P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const WorkItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
+        P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
+        P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
+        P.D = D; P.Dc = Dc; P.nprobe = nprobe; P.top_k = top_k; P.metric = ix->metric; P.ex_bits = ix->ex_bits;
+        const size_t lds = (size_t)Dc * 4 + (size_t)D * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 20 + kTileBlocks * 4 + 16;
+        hipError_t e;
+        if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
+        else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream);
+        else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream);
+        else e = launch_scan<0>(P, (uint32_t)nq, lds, stream);
+        HIP_TRY(e);
+    }
+    if (ix->profiling) { // algorithmic bytes of this scan launch: sum_q sum_{c in probe(q)} n_c * (D/8 + 12)
+        std::vector<unsigned long long> h(nq);
+        HIP_TRY(hipMemcpyAsync(h.data(), w->nvec.p, nq * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long tot = 0;
+        for (auto v : h) tot += v;
+        std::lock_guard<std::mutex> g(ix->mu);
+        ix->prof_scan_bytes += tot * (uint64_t)(D / 8 + 12);
+    }
+    return RBQ_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t rbq_abi_version(void) { return (1u << 16) | 0u; }
+
+const char* rbq_strerror(int code) {
+    switch (code) {
+        case RBQ_OK: return "ok";
+        case RBQ_DIMENSION_MISMATCH: return "dimension mismatch";
+        case RBQ_INVALID_CONFIG: return "invalid configuration";
+        case RBQ_EMPTY_INDEX: return "index is empty";
+        case RBQ_IO: return "io error";
+        case RBQ_INVALID_PERSISTENCE: return "invalid persisted index";
+        case RBQ_DEVICE: return "device error";
+        default: return "unknown error";
+    }
+}
+
+int rbq_last_error_detail(char* buf, size_t n) {
+    if (buf && n) {
+        size_t c = std::min(n - 1, g_err.size());
+        std::memcpy(buf, g_err.data(), c);
+        buf[c] = 0;
+    }
+    return (int)g_err.size();
+}
+
+int rbq_index_create(const rbq_header* hdr, const rbq_list_view* lists, int n_devices, const int* devices, rbq_index** out) {
+    g_err.clear();
+    return create_impl(hdr, lists, n_devices, devices, out);
+}
+
+void rbq_index_destroy(rbq_index* ix) { free_index(ix); }
+
+uint64_t rbq_index_len(const rbq_index* ix) { return ix ? ix->n_vectors : 0; }
+uint64_t rbq_index_cluster_count(const rbq_index* ix) { return ix ? ix->n_lists : 0; }
+uint32_t rbq_index_dim(const rbq_index* ix) { return ix ? ix->dim : 0; }
+uint32_t rbq_index_padded_dim(const rbq_index* ix) { return ix ? ix->D : 0; }
+
+// ---- RBQ1 v3 reader: load_from_reader, src/ivf.rs:1484-1702 --------------------------------------
+namespace {
+struct Reader {
+    const uint8_t* p; size_t len, off = 0;
+    bool take(void* dst, size_t n) { if (off + n > len || off + n < off) return false; std::memcpy(dst, p + off, n); off += n; return true; }
+    const uint8_t* view(size_t n) { if (off + n > len || off + n < off) return nullptr; const uint8_t* r = p + off; off += n; return r; }
+};
+uint32_t crc32_ieee(const uint8_t* p, size_t n) {
+    static uint32_t table[8][256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xff];
+    });
+    uint32_t crc = ~0u;
+    while (n >= 8) {
+        uint32_t a, b;
+        std::memcpy(&a, p, 4); std::memcpy(&b, p + 4, 4);
+        a ^= crc;
+        crc = table[7][a & 0xff] ^ table[6][(a >> 8) & 0xff] ^ table[5][(a >> 16) & 0xff] ^ table[4][a >> 24] ^
+              table[3][b & 0xff] ^ table[2][(b >> 8) & 0xff] ^ table[1][(b >> 16) & 0xff] ^ table[0][b >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = table[0][(crc ^ *p++) & 0xff] ^ (crc >> 8);
+    return ~crc;
+}
+} // namespace
+
+int rbq_index_load_rbq1(const void* bytes, size_t len, int n_devices, const int* devices, rbq_index** out) {
+    g_err.clear();
+    if (out) *out = nullptr;
+    if (!bytes) return fail(RBQ_IO, "null buffer");
+    Reader r{(const uint8_t*)bytes, len};
+    auto eof = [] { return fail(RBQ_IO, "failed to fill whole buffer"); };
+    char magic[4];
+    if (!r.take(magic, 4)) return eof();
+    if (std::memcmp(magic, "RBQ1", 4) != 0) return fail(RBQ_INVALID_PERSISTENCE, "unrecognized file header");
+    uint32_t version;
+    if (!r.take(&version, 4)) return eof();
+    if (version != 3) return fail(RBQ_INVALID_PERSISTENCE, "unsupported index format version (expected V3 with unified memory layout)");
+    rbq_header h;
+    std::memset(&h, 0, sizeof h);
+    uint8_t tags[4];
+    if (!r.take(&h.dim, 4)) return eof();
+    if (h.dim == 0) return fail(RBQ_INVALID_PERSISTENCE, "dimension must be positive");
+    if (!r.take(&h.padded_dim, 4)) return eof();
+    if (h.padded_dim < h.dim) return fail(RBQ_INVALID_PERSISTENCE, "padded_dim must be >= dim");
+    if (!r.take(tags, 4)) return eof();
+    if (tags[0] > 1) return fail(RBQ_INVALID_PERSISTENCE, "unknown metric tag");
+    if (tags[1] > 1) return fail(RBQ_INVALID_PERSISTENCE, "unknown rotator type tag");
+    if (tags[2] > 16) return fail(RBQ_INVALID_PERSISTENCE, "ex_bits out of range");
+    if (tags[3] == 0 || tags[3] > 16) return fail(RBQ_INVALID_PERSISTENCE, "total_bits out of range");
+    if ((uint8_t)(tags[3] - 1) != tags[2]) return fail(RBQ_INVALID_PERSISTENCE, "total_bits does not match ex_bits");
+    h.metric = tags[0]; h.rotator = tags[1]; h.ex_bits = tags[2];
+    uint64_t expected_vectors, cluster_count, rot_len;
+    if (!r.take(&expected_vectors, 8) || !r.take(&cluster_count, 8) || !r.take(&rot_len, 8)) return eof();
+    const uint8_t* blob = r.view(rot_len);
+    if (!blob) return eof();
+    h.rotator_blob = blob; h.rotator_len = rot_len; h.n_lists = cluster_count; h.n_vectors = expected_vectors;
+    { // DynamicRotator::deserialize length checks (src/rotation.rs:213-219,491-497)
+        const uint64_t want = h.rotator == RBQ_ROTATOR_FHT_KAC ? (uint64_t)4 * h.padded_dim / 8 : (uint64_t)h.padded_dim * h.padded_dim * 4;
+        if (rot_len != want)
+            return fail(RBQ_INVALID_PERSISTENCE, h.rotator == RBQ_ROTATOR_FHT_KAC ? "FHT rotator flip bits length mismatch" : "rotator matrix length mismatch");
+    }
+    if (cluster_count > (len / 8)) return eof(); // every cluster costs >= 8 bytes; guards the allocation below
+    const size_t D = h.padded_dim, stride = D * 4 + 384;
+    const size_t exb_expected = h.ex_bits ? D * h.ex_bits / 8 : 0;
+    std::vector<rbq_list_view> lists(cluster_count);
+    std::vector<std::vector<uint8_t>> ex_flat(cluster_count);
+    std::vector<std::vector<float>> fl(cluster_count); // centroid | f_add_ex | f_rescale_ex (alignment-safe copies)
+    std::vector<std::vector<uint64_t>> idv(cluster_count);
+    uint64_t actual = 0;
+    for (uint64_t c = 0; c < cluster_count; ++c) {
+        rbq_list_view& L = lists[c];
+        const uint8_t* cen = r.view(D * 4);
+        if (!cen) return eof();
+        uint64_t n;
+        if (!r.take(&n, 8)) return eof();
+        if (n > 1000000) return fail(RBQ_INVALID_PERSISTENCE, "cluster size exceeds reasonable limits - possible corruption");
+        const uint8_t* idp = r.view(n * 8);
+        if (!idp) return eof();
+        uint64_t blen;
+        if (!r.take(&blen, 8)) return eof();
+        if (blen != ((n + 31) / 32) * stride)
+            return fail(RBQ_INVALID_PERSISTENCE, "batch_data length mismatch - possible corruption or version incompatibility");
+        const uint8_t* bd = r.view(blen);
+        if (!bd) return eof();
+        ex_flat[c].resize(n * exb_expected);
+        for (uint64_t v = 0; v < n; ++v) {
+            uint64_t el;
+            if (!r.take(&el, 8)) return eof();
+            if (el != exb_expected)
+                return fail(RBQ_INVALID_PERSISTENCE, "ex_code_packed length mismatch - possible corruption or version incompatibility");
+            if (el && !r.take(&ex_flat[c][v * exb_expected], el)) return eof();
+        }
+        fl[c].resize(D + 2 * n);
+        std::memcpy(fl[c].data(), cen, D * 4);
+        if (!r.take(fl[c].data() + D, n * 4) || !r.take(fl[c].data() + D + n, n * 4)) return eof();
+        if (!r.view(n * 4) || !r.view(n * 4)) return eof(); // delta, vl: reconstruction only
+        idv[c].resize(n);
+        std::memcpy(idv[c].data(), idp, n * 8);
+        L.centroid = fl[c].data(); L.n = n; L.ids = idv[c].data(); L.batch_data = bd; L.batch_len = blen;
+        L.ex_codes = ex_flat[c].empty() ? nullptr : ex_flat[c].data();
+        L.f_add_ex = fl[c].data() + D; L.f_rescale_ex = fl[c].data() + D + n;
+        actual += n;
+    }
+    if (actual != expected_vectors) return fail(RBQ_INVALID_PERSISTENCE, "vector count metadata mismatch");
+    const size_t body_end = r.off;
+    uint32_t stored;
+    if (!r.take(&stored, 4)) return eof();
+    if (crc32_ieee((const uint8_t*)bytes + 8, body_end - 8) != stored) return fail(RBQ_INVALID_PERSISTENCE, "checksum mismatch");
+    // batch_data records are only byte-addressed by relayout_block (memcpy for the factor rows)
+    return create_impl(&h, lists.data(), n_devices, devices, out);
+}
+
+// ---- search ---------------------------------------------------------------------------------------
+static int check_query_args(const rbq_index* ix, uint32_t query_dim) {
+    if (!ix) return fail(RBQ_INVALID_CONFIG, "null index");
+    if (ix->n_vectors == 0) return fail(RBQ_EMPTY_INDEX, "index is empty");
+    if (query_dim != ix->dim) {
+        char b[96];
+        std::snprintf(b, sizeof b, "expected %u, got %u", ix->dim, query_dim);
+        return fail(RBQ_DIMENSION_MISMATCH, b);
+    }
+    return RBQ_OK;
+}
+
+int rbq_search_batch_device(const rbq_index* cix, const float* d_queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
+                            uint32_t nprobe, const uint32_t* d_filter_words, uint64_t filter_nbits, uint64_t* d_out_ids,
+                            float* d_out_scores, uint32_t* d_out_counts, rbq_diag* d_diag, void* hip_stream) {
+    g_err.clear();
+    rbq_index* ix = const_cast<rbq_index*>(cix);
+    int rc = check_query_args(ix, query_dim);
+    if (rc) return rc;
+    if (nq == 0) return RBQ_OK;
+    if (nq > 0x7fffffffull) return fail(RBQ_INVALID_CONFIG, "batch too large");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (top_k == 0) { // Ok(vec![]) for every query, src/ivf.rs:1792-1794
+        HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, s));
+        return RBQ_OK;
+    }
+    Workspace* w = take_ws(ix);
+    if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
+    rc = search_device(ix, w, d_queries, nq, top_k, nprobe, d_filter_words, filter_nbits, d_out_ids, d_out_scores,
+                       d_out_counts, d_diag, s);
+    // workspace buffers stay referenced by the enqueued kernels: hand the workspace back only after
+    // the caller's stream has drained them.
+    hipError_t e = hipStreamSynchronize(s);
+    give_ws(ix, w);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(RBQ_DEVICE, std::string("stream sync: ") + hipGetErrorString(e));
+    return RBQ_OK;
+}
+
+int rbq_search_batch(const rbq_index* cix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
+                     uint32_t nprobe, const uint32_t* filter_words, uint64_t filter_nbits, uint64_t* out_ids,
+                     float* out_scores, uint32_t* out_counts, rbq_diag* diag) {
+    g_err.clear();
+    rbq_index* ix = const_cast<rbq_index*>(cix);
+    int rc = check_query_args(ix, query_dim);
+    if (rc) return rc;
+    if (nq == 0) return RBQ_OK;
+    if (top_k == 0) {
+        if (out_counts) std::memset(out_counts, 0, nq * 4);
+        if (diag) std::memset(diag, 0, nq * sizeof(rbq_diag));
+        return RBQ_OK;
+    }
+    if (!queries || !out_ids || !out_scores || !out_counts) return fail(RBQ_INVALID_CONFIG, "null buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    Workspace* w = take_ws(ix);
+    if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
+    auto run = [&]() -> int {
+        int r2;
+        const uint64_t CH = 16384; // queries per device pass (bounds the nq x nlist score matrix)
+        if (filter_words) {
+            const size_t fb = (size_t)((filter_nbits + 31) / 32) * 4;
+            if ((r2 = w->filter.ensure(fb ? fb : 4))) return r2;
+            if (fb) HIP_TRY(hipMemcpyAsync(w->filter.p, filter_words, fb, hipMemcpyHostToDevice, w->stream));
+        }
+        for (uint64_t q0 = 0; q0 < nq; q0 += CH) {
+            const uint64_t n = std::min(CH, nq - q0);
+            if ((r2 = w->queries.ensure(n * query_dim * 4))) return r2;
+            if ((r2 = w->out_ids.ensure(n * top_k * 8))) return r2;
+            if ((r2 = w->out_scores.ensure(n * top_k * 4))) return r2;
+            if ((r2 = w->out_counts.ensure(n * 4))) return r2;
+            if (diag && (r2 = w->diag.ensure(n * sizeof(rbq_diag)))) return r2;
+            HIP_TRY(hipMemcpyAsync(w->queries.p, queries + q0 * query_dim, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
+            r2 = search_device(ix, w, (const float*)w->queries.p, n, top_k, nprobe,
+                               filter_words ? (const uint32_t*)w->filter.p : nullptr, filter_nbits, (uint64_t*)w->out_ids.p,
+                               (float*)w->out_scores.p, (uint32_t*)w->out_counts.p, diag ? (rbq_diag*)w->diag.p : nullptr,
+                               w->stream);
+            if (r2) return r2;
+            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, w->out_ids.p, n * top_k * 8, hipMemcpyDeviceToHost, w->stream));
+            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, w->out_scores.p, n * top_k * 4, hipMemcpyDeviceToHost, w->stream));
+            HIP_TRY(hipMemcpyAsync(out_counts + q0, w->out_counts.p, n * 4, hipMemcpyDeviceToHost, w->stream));
+            if (diag) HIP_TRY(hipMemcpyAsync(diag + q0, w->diag.p, n * sizeof(rbq_diag), hipMemcpyDeviceToHost, w->stream));
+            HIP_TRY(hipStreamSynchronize(w->stream));
+        }
+        return RBQ_OK;
+    };
+    rc = run();
+    if (rc) (void)hipStreamSynchronize(w->stream);
+    give_ws(ix, w);
+    return rc;
+}
+
+// ---- profiling taps ---------------------------------------------------------------------------------
+void rbq_profile_begin(rbq_index* ix) {
+    if (!ix) return;
+    std::lock_guard<std::mutex> g(ix->mu);
+    for (auto& sp : ix->prof) {
+        for (auto& e : sp.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        sp.ev.clear(); sp.ms = 0; sp.launches = 0;
+    }
+    ix->prof_scan_bytes = 0;
+    ix->profiling = true;
+}
+void rbq_profile_end(rbq_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->profiling = false;
+    for (auto& sp : ix->prof) {
+        for (auto& e : sp.ev) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sp.ms += ms; sp.launches++; }
+            (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+        }
+        sp.ev.clear();
+    }
+}
+double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* launches) {
+    if (!ix || !stage) return -1;
+    int s = !std::strcmp(stage, "prep") ? 0 : !std::strcmp(stage, "rank") ? 1 : !std::strcmp(stage, "scan") ? 2 : -1;
+    if (s < 0) return -1;
+    if (launches) *launches = ix->prof[s].launches;
+    return ix->prof[s].launches ? ix->prof[s].ms / (double)ix->prof[s].launches : 0.0;
+}
+uint64_t rbq_profile_scan_bytes(const rbq_index* ix) { return ix ? ix->prof_scan_bytes : 0; }
+
+} // extern "C"

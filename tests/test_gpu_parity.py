@@ -1,0 +1,137 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, include/rbq.h) against the CPU oracle on the
+same seeded inputs.  Bar: ids identical, counts identical, scores within 1e-4 relative (BASELINE.json
+north_star); the diag counters (SearchDiagnostics, reference src/ivf.rs:150-155) are compared exactly too.
+Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+import rabitq_rs_amd as rq
+from conftest import build_index, make_dataset
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north_star tolerance for f32 scores
+
+
+def _compare(built, idx, queries, top_k, nprobe, filter_words=None, filter_nbits=0):
+    rc, oids, osc, ocnt, odiag = oracle.search_batch(built, queries, top_k, nprobe, filter_words, filter_nbits,
+                                                     want_diag=True)
+    assert rc == 0
+    ids, sc, cnt, diag = idx.batch_search_raw(queries, rq.SearchParams(top_k, nprobe), filter_words, filter_nbits,
+                                              want_diag=True)
+    assert np.array_equal(cnt, ocnt), f"counts differ: {np.nonzero(cnt != ocnt)[0][:10]}"
+    bad = np.nonzero((ids != oids).any(axis=1))[0]
+    assert bad.size == 0, f"ids differ for queries {bad[:10]}: gpu={ids[bad[0]]} oracle={oids[bad[0]]}"
+    for q in range(ids.shape[0]):
+        c = int(cnt[q])
+        np.testing.assert_allclose(sc[q, :c], osc[q, :c], rtol=RTOL, atol=0)
+        assert np.isnan(sc[q, c:]).all() and (ids[q, c:] == np.iinfo(np.uint64).max).all()
+    assert np.array_equal(diag, odiag), "SearchDiagnostics counters differ"
+    return ids, sc, cnt
+
+
+CASES = [
+    # n, dim, nlist, bits, metric, rotator, nq, top_k, nprobe, uniform
+    pytest.param(10000, 128, 256, 7, 0, 1, 64, 10, 32, True, id="cfg1_10k_d128_7bit_L2"),
+    pytest.param(6000, 960, 48, 7, 0, 1, 48, 10, 12, False, id="gist_shape_d960_7bit_L2"),
+    pytest.param(6000, 960, 48, 3, 1, 1, 48, 10, 16, False, id="gist_shape_d960_3bit_IP"),
+    pytest.param(5000, 768, 40, 7, 0, 1, 32, 10, 10, False, id="d768_7bit_L2"),
+    pytest.param(4000, 128, 32, 1, 0, 1, 32, 10, 8, False, id="d128_1bit_L2"),
+    pytest.param(4000, 128, 32, 1, 1, 1, 32, 10, 8, False, id="d128_1bit_IP"),
+    pytest.param(4000, 100, 32, 7, 0, 1, 32, 10, 8, False, id="d100_pad128_kac_7bit_L2"),
+    pytest.param(3000, 200, 24, 3, 0, 1, 32, 5, 24, False, id="d200_pad256_3bit_all_lists"),
+    pytest.param(3000, 64, 24, 7, 1, 0, 32, 10, 6, False, id="matrix_rotator_d64_7bit_IP"),
+    pytest.param(3000, 48, 24, 3, 0, 0, 32, 10, 6, False, id="matrix_rotator_d48_codepad_3bit_L2"),
+    pytest.param(5000, 320, 40, 7, 0, 1, 16, 100, 20, False, id="d320_top100"),
+    pytest.param(2000, 64, 16, 7, 0, 1, 16, 1, 4, False, id="top1"),
+]
+
+
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,rot,nq,top_k,nprobe,uniform", CASES)
+def test_search_matches_oracle(n, dim, nlist, bits, metric, rot, nq, top_k, nprobe, uniform):
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot,
+                              uniform=uniform, normalize=(metric == 1), seed=1000 + dim + bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    assert len(idx) == n and idx.cluster_count() == nlist and idx.dim == dim
+    queries = make_dataset(nq, dim, max(nlist // 4, 1), 4242, normalize=(metric == 1), uniform=uniform)
+    _compare(built, idx, queries, top_k, nprobe)
+    # queries taken from the data itself (near-zero residuals, exact hits)
+    _compare(built, idx, data[:8], top_k, nprobe)
+    idx.close()
+
+
+def test_nprobe_clamp_and_small_counts():
+    data, built = build_index(n=300, dim=64, nlist=8, total_bits=7)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(8, 64, 2, 7)
+    _compare(built, idx, q, 10, 0)       # nprobe clamped up to 1
+    _compare(built, idx, q, 10, 1000)    # clamped down to nlist
+    _compare(built, idx, q, 400, 8)      # top_k > n: counts < top_k, padded with UINT64_MAX / NaN
+    idx.close()
+
+
+def test_filtered_search_matches_oracle():
+    data, built = build_index(n=5000, dim=128, nlist=32, total_bits=7)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(16, 128, 8, 11)
+    rng = np.random.default_rng(5)
+    allowed = rng.choice(5000, 700, replace=False)
+    nbits = int(allowed.max()) + 1
+    words = np.zeros((nbits + 31) // 32, np.uint32)
+    np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+    ids, sc, cnt = _compare(built, idx, q, 10, 16, words, nbits)
+    assert set(ids[cnt[:, None] > np.arange(10)[None, :]].tolist()) <= set(allowed.tolist())
+    # empty filter -> empty result (reference src/tests.rs:753-909)
+    _compare(built, idx, q, 10, 16, np.zeros(1, np.uint32), 0)
+    idx.close()
+
+
+def test_rbq1_round_trip_identical_results():
+    """save -> load_rbq1 -> search equals search on the created index (reference src/tests.rs:394-431)."""
+    data, built = build_index(n=3000, dim=128, nlist=24, total_bits=7)
+    blob = built.save_rbq1()
+    a = rq.IvfRabitqIndex.from_built(built)
+    b = rq.IvfRabitqIndex.load_from_bytes(blob)
+    q = make_dataset(32, 128, 6, 3)
+    ra = a.batch_search_raw(q, rq.SearchParams(10, 8))
+    rb = b.batch_search_raw(q, rq.SearchParams(10, 8))
+    assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[2], rb[2])
+    assert np.array_equal(ra[1].view(np.uint32), rb[1].view(np.uint32))  # bit-equal scores
+    _compare(built, b, q, 10, 8)
+    a.close(); b.close()
+
+
+def test_api_semantics_on_device():
+    data, built = build_index(n=1000, dim=64, nlist=8, total_bits=7)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    with pytest.raises(rq.RabitqError) as e:
+        idx.search(np.zeros(63, np.float32), rq.SearchParams(10, 4))
+    assert e.value.kind == "DimensionMismatch" and "expected 64, got 63" in e.value.detail
+    assert idx.search(data[0], rq.SearchParams(0, 4)) == []  # top_k == 0 -> Ok(vec![])
+    res = idx.search(data[0], rq.SearchParams(5, 8))
+    assert len(res) == 5 and all(isinstance(r.id, int) for r in res)
+    assert [r.score for r in res] == sorted(r.score for r in res)  # L2: ascending distance
+    bq = idx.batch_query(data[:3], 5, 8)
+    assert len(bq) == 3 and bq[0].shape == (5, 2) and bq[0].dtype == np.float32
+    idx.close()
+
+
+def test_large_batch_property_checks():
+    """BASELINE-sized batch (nq=1024) through size-independent properties: sortedness, ids drawn from the
+    probed lists, idempotence, and batch == one-at-a-time."""
+    data, built = build_index(n=20000, dim=128, nlist=64, total_bits=7)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(1024, 128, 16, 77)
+    ids, sc, cnt, _ = idx.batch_search_raw(q, rq.SearchParams(10, 16))
+    ids2, sc2, cnt2, _ = idx.batch_search_raw(q, rq.SearchParams(10, 16))
+    assert np.array_equal(ids, ids2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    assert (cnt == 10).all()
+    assert (np.diff(sc, axis=1) >= 0).all()
+    for i in (0, 511, 1023):
+        one = idx.batch_search_raw(q[i], rq.SearchParams(10, 16))
+        assert np.array_equal(one[0][0], ids[i])
+    rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, 10, 16)
+    assert np.array_equal(ids, oids)
+    np.testing.assert_allclose(sc, osc, rtol=RTOL)
+    idx.close()
