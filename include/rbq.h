@@ -126,8 +126,8 @@ int rbq_search_batch(const rbq_index* idx, const float* queries, uint64_t nq,
 
 /* Same operation on DEVICE pointers (queries and outputs already in HBM of the
  * index's device), enqueued on `hip_stream` (a hipStream_t passed as void*,
- * NULL = default stream) without host synchronisation. d_filter_words may be
- * NULL. d_diag is NULL or [nq] rbq_diag in device memory. */
+ * NULL = default stream); returns once the batch has completed on that stream
+ * (the per-call workspace is recycled on return). d_filter_words may be NULL. d_diag is NULL or [nq] rbq_diag in device memory. */
 int rbq_search_batch_device(const rbq_index* idx, const float* d_queries, uint64_t nq,
                             uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
                             const uint32_t* d_filter_words, uint64_t filter_nbits,
@@ -137,7 +137,7 @@ int rbq_search_batch_device(const rbq_index* idx, const float* d_queries, uint64
 
 /* Timing taps for bench.py: average duration (ms) of each stage kernel between
  * rbq_profile_begin/end, measured with hipEvents on the stream the kernels run
- * on. stage names: "prep", "rank", "scan". Returns <0 for an unknown stage. */
+ * on. stage names: "prep", "rank", "select", "scan". Returns <0 for an unknown stage. */
 void   rbq_profile_begin(rbq_index* idx);
 void   rbq_profile_end(rbq_index* idx);
 double rbq_profile_stage_ms(const rbq_index* idx, const char* stage, uint64_t* launches);

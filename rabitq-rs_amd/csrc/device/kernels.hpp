@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
                                                      const uint32_t* __restrict__ list_n,
                                                      ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
                                                      uint64_t wl_stride, uint32_t* __restrict__ nstream,
-                                                     unsigned long long* __restrict__ nvec_probed) {
+                                                     unsigned long long* __restrict__ nvec_probed,
+                                                     unsigned long long* __restrict__ prof_total) {
     extern __shared__ __align__(16) unsigned char smraw[];
     uint64_t* sel = reinterpret_cast<uint64_t*>(smraw);
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)np2 * 8);
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
         for (uint32_t i = 0; i < kThreads; ++i) { uint32_t v = part[i]; part[i] = run; run += v; }
         nstream[q] = run;
         nvec_probed[q] = s_nvec; // sum of n_c over the probed lists: the scan's algorithmic work
+        if (prof_total) atomicAdd(prof_total, s_nvec);
     }
     __syncthreads();
     uint64_t pos = (uint64_t)q * wl_stride + part[tid];

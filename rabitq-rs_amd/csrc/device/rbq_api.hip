@@ -82,7 +82,7 @@ struct rbq_index {
     float fac = 1.0f;
     // device arrays
     void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
-         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr;
+         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr;
     // host
     std::vector<uint32_t> h_list_n;
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
@@ -90,9 +90,8 @@ struct rbq_index {
     std::vector<Workspace*> pool;
     // profiling
     bool profiling = false;
-    StageProf prof[3]; // prep, rank(+select), scan
+    StageProf prof[4]; // prep, rank, select, scan
     uint64_t prof_scan_bytes = 0;
-    std::vector<std::pair<void*, uint64_t>> prof_pending_nstream; // unused placeholder
 };
 
 namespace {
@@ -101,7 +100,7 @@ void free_index(rbq_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (void* p : {ix->d_rot_blob, ix->d_centroids, ix->d_blocks, ix->d_ids, ix->d_ex, ix->d_fadd_ex, ix->d_fres_ex,
-                    ix->d_list_gb0, ix->d_list_n})
+                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total})
         if (p) (void)hipFree(p);
     for (Workspace* w : ix->pool) { w->release(); delete w; }
     for (auto& sp : ix->prof)
@@ -238,6 +237,7 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     } while (0)
     UP(d_rot_blob, blob); UP(d_centroids, cent); UP(d_blocks, blocks); UP(d_ids, ids); UP(d_ex, ex);
     UP(d_fadd_ex, fa); UP(d_fres_ex, fr); UP(d_list_gb0, gb0); UP(d_list_n, ln);
+    { std::vector<unsigned long long> z(1, 0); UP(d_prof_total, z); }
 #undef UP
     *out = ix;
     return RBQ_OK;
@@ -323,15 +323,19 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
                                (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
         HIP_TRY(hipGetLastError());
+    }
+    {
+        ProfScope ps(ix, 2, stream);
         const size_t lds = (size_t)np2 * 8 + (size_t)D * 4 + kThreads * 4;
         hipLaunchKernelGGL(k_select, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (const float*)w->scores.p, nlist, nprobe,
                            np2, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
                            (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
-                           (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p);
+                           (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
+                           ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr);
         HIP_TRY(hipGetLastError());
     }
     {
-        ProfScope ps(ix, 2, stream);
+        ProfScope ps(ix, 3, stream);
         ScanParams P;
         P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
         P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
@@ -347,15 +351,6 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream);
         else e = launch_scan<0>(P, (uint32_t)nq, lds, stream);
         HIP_TRY(e);
-    }
-    if (ix->profiling) { // algorithmic bytes of this scan launch: sum_q sum_{c in probe(q)} n_c * (D/8 + 12)
-        std::vector<unsigned long long> h(nq);
-        HIP_TRY(hipMemcpyAsync(h.data(), w->nvec.p, nq * 8, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        unsigned long long tot = 0;
-        for (auto v : h) tot += v;
-        std::lock_guard<std::mutex> g(ix->mu);
-        ix->prof_scan_bytes += tot * (uint64_t)(D / 8 + 12);
     }
     return RBQ_OK;
 }
@@ -621,6 +616,8 @@ void rbq_profile_begin(rbq_index* ix) {
         sp.ev.clear(); sp.ms = 0; sp.launches = 0;
     }
     ix->prof_scan_bytes = 0;
+    (void)hipSetDevice(ix->device);
+    (void)hipMemset(ix->d_prof_total, 0, 8);
     ix->profiling = true;
 }
 void rbq_profile_end(rbq_index* ix) {
@@ -629,6 +626,11 @@ void rbq_profile_end(rbq_index* ix) {
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> g(ix->mu);
     ix->profiling = false;
+    {
+        unsigned long long tot = 0;
+        (void)hipMemcpy(&tot, ix->d_prof_total, 8, hipMemcpyDeviceToHost);
+        ix->prof_scan_bytes = tot * (uint64_t)(ix->D / 8 + 12); // sum_q sum_{c in probe(q)} n_c * (D/8 + 12)
+    }
     for (auto& sp : ix->prof) {
         for (auto& e : sp.ev) {
             float ms = 0;
@@ -640,7 +642,7 @@ void rbq_profile_end(rbq_index* ix) {
 }
 double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* launches) {
     if (!ix || !stage) return -1;
-    int s = !std::strcmp(stage, "prep") ? 0 : !std::strcmp(stage, "rank") ? 1 : !std::strcmp(stage, "scan") ? 2 : -1;
+    int s = !std::strcmp(stage, "prep") ? 0 : !std::strcmp(stage, "rank") ? 1 : !std::strcmp(stage, "select") ? 2 : !std::strcmp(stage, "scan") ? 3 : -1;
     if (s < 0) return -1;
     if (launches) *launches = ix->prof[s].launches;
     return ix->prof[s].launches ? ix->prof[s].ms / (double)ix->prof[s].launches : 0.0;
