@@ -530,13 +530,28 @@ struct ScanParams {
     uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
 };
 
-constexpr int kTileBlocks = 8;              // 32-vector blocks per tile (1 per half-wave)
+#ifndef RBQ_TILE_U
+#define RBQ_TILE_U 1
+#endif
+#ifndef RBQ_SCAN_WAVES
+#define RBQ_SCAN_WAVES 4
+#endif
+constexpr int kTileU = RBQ_TILE_U;          // 32-vector blocks per half-wave per tile
+constexpr int kTileBlocks = 8 * kTileU;     // blocks per tile
 constexpr int kTileCand = kTileBlocks * 32; // 512 candidates
 
 // 8 nibble lookups of one little-endian code dword; table p+16*m serves nibble m.
 // The empty asm pins the running sum so the integer adds are not re-associated into one big
 // end-of-block reduction (which made hipcc spill every ds_read result to scratch).
-__device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, const uint8_t* p) {
+#ifndef RBQ_PIN_MODE
+#define RBQ_PIN_MODE 1
+#endif
+// LUT pointer in the LDS address space, formed from a plain integer offset.  A pointer derived from the
+// `extern __shared__` symbol carries a link-time relocation that hipcc adds with one v_add_u32 PER LOOKUP
+// (`v_add_u32 v, 0, v` after linking); an integer-derived address lets the codebook offset fold into the
+// ds_read_u8 immediate.  k_scan keeps its LUT at LDS byte 0 and traps if the dynamic region is not there.
+typedef const __attribute__((address_space(3))) uint8_t* lds_lut_ptr;
+__device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, lds_lut_ptr p) {
     uint32_t s = p[x & 15u];
     s += p[16 + ((x >> 4) & 15u)];
     s += p[32 + ((x >> 8) & 15u)];
@@ -546,12 +561,16 @@ __device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, const uint8_t* 
     s += p[96 + ((x >> 24) & 15u)];
     s += p[112 + (x >> 28)];
     acc += s;
+#if RBQ_PIN_MODE == 0
     asm volatile("" : "+v"(acc));
+#elif RBQ_PIN_MODE == 1
+    asm("" : "+v"(acc));
+#endif
 }
 
 // Sum over all Dc/4 codebooks of lut[codebook][nibble] for one vector (lane l32 of a block).
 template <int DT>
-__device__ __forceinline__ uint32_t accumulate_block(const uint8_t* __restrict__ blk, const uint8_t* lut,
+__device__ __forceinline__ uint32_t accumulate_block(const uint8_t* __restrict__ blk, lds_lut_ptr lut,
                                                      uint32_t l32, uint32_t Drt) {
     const uint32_t D = DT ? (uint32_t)DT : Drt;
     const uint32_t G16 = D >> 7;
@@ -589,7 +608,7 @@ __device__ __forceinline__ uint32_t accumulate_block(const uint8_t* __restrict__
 // LDS carve-up of k_scan (dynamic): lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 |
 // q_slot,q_lb,q_ip,q_gadd,q_d [kTileCand] | cnt[kTileBlocks]
 template <int DT>
-__global__ __launch_bounds__(kThreads, 4) void k_scan(ScanParams P) {
+__global__ __launch_bounds__(kThreads, RBQ_SCAN_WAVES) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smraw[];
     const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
     const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
@@ -611,6 +630,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan(ScanParams P) {
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t lane = tid & 63u, half = lane >> 5, l32 = lane & 31u, hw = tid >> 5; // hw: half-wave 0..7
+    const lds_lut_ptr lut0 = (lds_lut_ptr)(uint32_t)0; // == s_lut, see look8
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smraw != 0u) __builtin_trap();
     const uint32_t top_k = P.top_k, ex_bits = P.ex_bits;
     const size_t stride = (size_t)Dc * 4 + 384;
 
@@ -633,54 +654,63 @@ __global__ __launch_bounds__(kThreads, 4) void k_scan(ScanParams P) {
 
     for (uint32_t t0 = 0; t0 < ns; t0 += kTileBlocks) {
         const float T = s_T;
-        const uint32_t s = t0 + hw;
-        bool surv = false;
-        uint32_t slot = 0;
-        float v_lb = 0.0f, v_ip = 0.0f, v_est = 0.0f, v_gadd = 0.0f;
-        if (s < ns) {
-            const WorkItem wi = wl[s];
-            const uint32_t rank = wi.rank_nvalid >> 6, nvalid = wi.rank_nvalid & 63u;
-            const uint8_t* blk = P.blocks + (size_t)wi.gblock * stride;
-            const uint32_t accu = accumulate_block<DT>(blk, s_lut, l32, Dc) & 0xffffu;
-            const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
-            const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
-            const ProbeInfo pi = probe[rank];
-            // compute_batch_distances_u16 (AVX2 body): only the first op is fused
-            const float ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
-            const float tt = ip + qc.k1x;
-            const float rs = f_rescale * tt;
-            float est = f_add + pi.g_add;
-            est = est + rs;
-            const float er = f_error * pi.g_err;
-            float lb = est - er;
-            slot = wi.gblock * 32u + l32;
-            bool valid = l32 < nvalid;
-            if (valid && P.filter) {
-                const uint32_t id32 = (uint32_t)P.ids[slot];
-                valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
+        bool surv[kTileU];
+        uint32_t slot[kTileU], mask32[kTileU];
+        float v_lb[kTileU], v_ip[kTileU], v_est[kTileU], v_gadd[kTileU];
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            const uint32_t s = t0 + hw * kTileU + u;
+            surv[u] = false; slot[u] = 0;
+            v_lb[u] = 0.0f; v_ip[u] = 0.0f; v_est[u] = 0.0f; v_gadd[u] = 0.0f;
+            if (s < ns) {
+                const WorkItem wi = wl[s];
+                const uint32_t rank = wi.rank_nvalid >> 6, nvalid = wi.rank_nvalid & 63u;
+                const uint8_t* blk = P.blocks + (size_t)wi.gblock * stride;
+                const uint32_t accu = accumulate_block<DT>(blk, lut0, l32, Dc) & 0xffffu;
+                const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
+                const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
+                const ProbeInfo pi = probe[rank];
+                // compute_batch_distances_u16 (AVX2 body): only the first op is fused
+                const float ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
+                const float tt = ip + qc.k1x;
+                const float rs = f_rescale * tt;
+                float est = f_add + pi.g_add;
+                est = est + rs;
+                const float er = f_error * pi.g_err;
+                float lb = est - er;
+                slot[u] = wi.gblock * 32u + l32;
+                bool valid = l32 < nvalid;
+                if (valid && P.filter) {
+                    const uint32_t id32 = (uint32_t)P.ids[slot[u]];
+                    valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
+                }
+                if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(pi.dotqc + qc.qnorm);
+                surv[u] = valid && (lb < T);
+                if (valid && !surv[u]) ++n_skip;
+                v_lb[u] = lb; v_ip[u] = ip; v_est[u] = est; v_gadd[u] = pi.g_add;
             }
-            if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(pi.dotqc + qc.qnorm);
-            surv = valid && (lb < T);
-            if (valid && !surv) ++n_skip;
-            v_lb = lb; v_ip = ip; v_est = est; v_gadd = pi.g_add;
+            const unsigned long long bal = __ballot(surv[u]);
+            mask32[u] = (uint32_t)(bal >> (half * 32));
+            if (l32 == 0) s_cnt[hw * kTileU + u] = __popc(mask32[u]);
         }
-        const unsigned long long bal = __ballot(surv);
-        const uint32_t mask32 = (uint32_t)(bal >> (half * 32));
-        if (l32 == 0) s_cnt[hw] = __popc(mask32);
         __syncthreads();
         uint32_t S = 0, base = 0;
         for (uint32_t j = 0; j < (uint32_t)kTileBlocks; ++j) {
             const uint32_t c = s_cnt[j];
-            base += j < hw ? c : 0u;
+            base += j < hw * kTileU ? c : 0u;
             S += c;
         }
-        if (surv) {
-            const uint32_t pos = base + __popc(mask32 & ((1u << l32) - 1u));
-            q_slot[pos] = slot;
-            q_lb[pos] = v_lb;
-            q_ip[pos] = v_ip;
-            q_gadd[pos] = v_gadd;
-            q_d[pos] = v_est;
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            if (surv[u]) {
+                const uint32_t pos = base + __popc(mask32[u] & ((1u << l32) - 1u));
+                q_slot[pos] = slot[u];
+                q_lb[pos] = v_lb[u];
+                q_ip[pos] = v_ip[u];
+                q_gadd[pos] = v_gadd[u];
+                q_d[pos] = v_est[u];
+            }
+            base += __popc(mask32[u]);
         }
         if (S == 0) { __syncthreads(); continue; } // uniform
         __syncthreads();

@@ -8,7 +8,7 @@ from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-LIB_PATH = os.path.join(_HERE, "csrc", "librbq.so")
+LIB_PATH = os.environ.get("RBQ_LIB_PATH") or os.path.join(_HERE, "csrc", "librbq.so")  # override: kernel A/B builds
 
 
 def lib():
