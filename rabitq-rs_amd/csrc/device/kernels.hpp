@@ -505,367 +505,4 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_scan
-// ---------------------------------------------------------------------------------------------
-struct ScanParams {
-    const uint8_t* blocks;   // [n_blocks][4Dc + 384]: lane-major sign codes | f_add[32] | f_rescale[32] | f_error[32]
-    const uint64_t* ids;     // [n_blocks*32]
-    const uint8_t* ex_codes; // [n_blocks*32][D*ex/8]   (reference packed layout per vector)
-    const float* f_add_ex;   // [n_blocks*32]
-    const float* f_rescale_ex;
-    const uint8_t* lut;      // [nq][4Dc] (pair-swapped codebook order); Dc = D rounded up to x64
-    const float* rot;        // [nq][D]
-    const QueryConsts* consts;
-    const ProbeInfo* probe;  // [nq][nprobe]
-    const WorkItem* wl;      // [nq][wl_stride]
-    const uint32_t* nstream; // [nq]
-    const uint32_t* filter;  // dense bitset or null
-    uint64_t filter_nbits;
-    uint64_t wl_stride;
-    uint64_t* out_ids;
-    float* out_scores;
-    uint32_t* out_counts;
-    unsigned long long* diag; // [nq][3] or null
-    uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
-};
-
-#ifndef RBQ_TILE_U
-#define RBQ_TILE_U 1
-#endif
-#ifndef RBQ_SCAN_WAVES
-#define RBQ_SCAN_WAVES 4
-#endif
-constexpr int kTileU = RBQ_TILE_U;          // 32-vector blocks per half-wave per tile
-constexpr int kTileBlocks = 8 * kTileU;     // blocks per tile
-constexpr int kTileCand = kTileBlocks * 32; // 512 candidates
-
-// 8 nibble lookups of one little-endian code dword; table p+16*m serves nibble m.
-// The empty asm pins the running sum so the integer adds are not re-associated into one big
-// end-of-block reduction (which made hipcc spill every ds_read result to scratch).
-#ifndef RBQ_PIN_MODE
-#define RBQ_PIN_MODE 1
-#endif
-// LUT pointer in the LDS address space, formed from a plain integer offset.  A pointer derived from the
-// `extern __shared__` symbol carries a link-time relocation that hipcc adds with one v_add_u32 PER LOOKUP
-// (`v_add_u32 v, 0, v` after linking); an integer-derived address lets the codebook offset fold into the
-// ds_read_u8 immediate.  k_scan keeps its LUT at LDS byte 0 and traps if the dynamic region is not there.
-typedef const __attribute__((address_space(3))) uint8_t* lds_lut_ptr;
-__device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, lds_lut_ptr p) {
-    uint32_t s = p[x & 15u];
-    s += p[16 + ((x >> 4) & 15u)];
-    s += p[32 + ((x >> 8) & 15u)];
-    s += p[48 + ((x >> 12) & 15u)];
-    s += p[64 + ((x >> 16) & 15u)];
-    s += p[80 + ((x >> 20) & 15u)];
-    s += p[96 + ((x >> 24) & 15u)];
-    s += p[112 + (x >> 28)];
-    acc += s;
-#if RBQ_PIN_MODE == 0
-    asm volatile("" : "+v"(acc));
-#elif RBQ_PIN_MODE == 1
-    asm("" : "+v"(acc));
-#endif
-}
-
-// Sum over all Dc/4 codebooks of lut[codebook][nibble] for one vector (lane l32 of a block).
-template <int DT>
-__device__ __forceinline__ uint32_t accumulate_block(const uint8_t* __restrict__ blk, lds_lut_ptr lut,
-                                                     uint32_t l32, uint32_t Drt) {
-    const uint32_t D = DT ? (uint32_t)DT : Drt;
-    const uint32_t G16 = D >> 7;
-    const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
-    uint32_t acc = 0;
-    if (DT) {
-        uint4 x[(DT >> 7) ? (DT >> 7) : 1];
-#pragma unroll
-        for (uint32_t g = 0; g < (DT >> 7); ++g) x[g] = cp[g * 32]; // all code granules in flight first
-#pragma unroll
-        for (uint32_t g = 0; g < (DT >> 7); ++g) {
-            look8(acc, x[g].x, lut + g * 512);
-            look8(acc, x[g].y, lut + g * 512 + 128);
-            look8(acc, x[g].z, lut + g * 512 + 256);
-            look8(acc, x[g].w, lut + g * 512 + 384);
-        }
-    } else {
-        for (uint32_t g = 0; g < G16; ++g) {
-            uint4 x = cp[g * 32];
-            look8(acc, x.x, lut + g * 512);
-            look8(acc, x.y, lut + g * 512 + 128);
-            look8(acc, x.z, lut + g * 512 + 256);
-            look8(acc, x.w, lut + g * 512 + 384);
-        }
-    }
-    if (D & 64u) {
-        const uint2* tp = reinterpret_cast<const uint2*>(blk + G16 * 512) + l32;
-        uint2 y = *tp;
-        look8(acc, y.x, lut + G16 * 512);
-        look8(acc, y.y, lut + G16 * 512 + 128);
-    }
-    return acc;
-}
-
-// LDS carve-up of k_scan (dynamic): lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 |
-// q_slot,q_lb,q_ip,q_gadd,q_d [kTileCand] | cnt[kTileBlocks]
-template <int DT>
-__global__ __launch_bounds__(kThreads, RBQ_SCAN_WAVES) void k_scan(ScanParams P) {
-    extern __shared__ __align__(16) unsigned char smraw[];
-    const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
-    const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
-    uint8_t* s_lut = smraw;
-    float* s_q = reinterpret_cast<float*>(smraw + (size_t)Dc * 4);
-    float* heap_d = s_q + D;
-    uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
-    uint32_t* q_slot = heap_s + (P.top_k + 1);
-    float* q_lb = reinterpret_cast<float*>(q_slot + kTileCand);
-    float* q_ip = q_lb + kTileCand;
-    float* q_gadd = q_ip + kTileCand;
-    float* q_d = q_gadd + kTileCand;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(q_d + kTileCand);
-    // no static __shared__ in this kernel: the dynamic region must start at LDS address 0 so that the
-    // LUT offsets fold into the ds_read_u8 immediate (saves one VALU add per lookup)
-    float& s_T = *reinterpret_cast<float*>(s_cnt + kTileBlocks);
-    uint32_t& s_len = *(s_cnt + kTileBlocks + 1);
-    uint32_t* s_nskip = s_cnt + kTileBlocks + 2;
-
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, half = lane >> 5, l32 = lane & 31u, hw = tid >> 5; // hw: half-wave 0..7
-    const lds_lut_ptr lut0 = (lds_lut_ptr)(uint32_t)0; // == s_lut, see look8
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smraw != 0u) __builtin_trap();
-    const uint32_t top_k = P.top_k, ex_bits = P.ex_bits;
-    const size_t stride = (size_t)Dc * 4 + 384;
-
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
-        uint4* dst = reinterpret_cast<uint4*>(s_lut);
-        for (uint32_t i = tid; i < Dc / 4; i += kThreads) dst[i] = src[i];
-        for (uint32_t i = tid; i < D; i += kThreads) s_q[i] = P.rot[(size_t)q * D + i];
-        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; }
-    }
-    const QueryConsts qc = P.consts[q];
-    const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
-    const WorkItem* wl = P.wl + (size_t)q * P.wl_stride;
-    const uint32_t ns = P.nstream[q];
-    __syncthreads();
-
-    uint32_t heap_len = 0;                    // thread 0 only
-    uint32_t n_skip = 0, n_ext = 0, n_est = 0; // diag (n_skip: every thread; others thread 0)
-    const uint32_t exb = D * ex_bits / 8;
-
-    for (uint32_t t0 = 0; t0 < ns; t0 += kTileBlocks) {
-        const float T = s_T;
-        bool surv[kTileU];
-        uint32_t slot[kTileU], mask32[kTileU];
-        float v_lb[kTileU], v_ip[kTileU], v_est[kTileU], v_gadd[kTileU];
-#pragma unroll
-        for (int u = 0; u < kTileU; ++u) {
-            const uint32_t s = t0 + hw * kTileU + u;
-            surv[u] = false; slot[u] = 0;
-            v_lb[u] = 0.0f; v_ip[u] = 0.0f; v_est[u] = 0.0f; v_gadd[u] = 0.0f;
-            if (s < ns) {
-                const WorkItem wi = wl[s];
-                const uint32_t rank = wi.rank_nvalid >> 6, nvalid = wi.rank_nvalid & 63u;
-                const uint8_t* blk = P.blocks + (size_t)wi.gblock * stride;
-                const uint32_t accu = accumulate_block<DT>(blk, lut0, l32, Dc) & 0xffffu;
-                const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
-                const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
-                const ProbeInfo pi = probe[rank];
-                // compute_batch_distances_u16 (AVX2 body): only the first op is fused
-                const float ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
-                const float tt = ip + qc.k1x;
-                const float rs = f_rescale * tt;
-                float est = f_add + pi.g_add;
-                est = est + rs;
-                const float er = f_error * pi.g_err;
-                float lb = est - er;
-                slot[u] = wi.gblock * 32u + l32;
-                bool valid = l32 < nvalid;
-                if (valid && P.filter) {
-                    const uint32_t id32 = (uint32_t)P.ids[slot[u]];
-                    valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
-                }
-                if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(pi.dotqc + qc.qnorm);
-                surv[u] = valid && (lb < T);
-                if (valid && !surv[u]) ++n_skip;
-                v_lb[u] = lb; v_ip[u] = ip; v_est[u] = est; v_gadd[u] = pi.g_add;
-            }
-            const unsigned long long bal = __ballot(surv[u]);
-            mask32[u] = (uint32_t)(bal >> (half * 32));
-            if (l32 == 0) s_cnt[hw * kTileU + u] = __popc(mask32[u]);
-        }
-        __syncthreads();
-        uint32_t S = 0, base = 0;
-        for (uint32_t j = 0; j < (uint32_t)kTileBlocks; ++j) {
-            const uint32_t c = s_cnt[j];
-            base += j < hw * kTileU ? c : 0u;
-            S += c;
-        }
-#pragma unroll
-        for (int u = 0; u < kTileU; ++u) {
-            if (surv[u]) {
-                const uint32_t pos = base + __popc(mask32[u] & ((1u << l32) - 1u));
-                q_slot[pos] = slot[u];
-                q_lb[pos] = v_lb[u];
-                q_ip[pos] = v_ip[u];
-                q_gadd[pos] = v_gadd[u];
-                q_d[pos] = v_est[u];
-            }
-            base += __popc(mask32[u]);
-        }
-        if (S == 0) { __syncthreads(); continue; } // uniform
-        __syncthreads();
-
-        if (ex_bits) { // ex-code refine: 16 lanes per survivor, AVX-512 lane order + halving tree
-            const uint32_t gl = tid & 15u, grp = tid >> 4;
-            const uint32_t sh_hi = 8u * (gl & 3u) + 2u * (gl >> 2);
-            const uint32_t sh_lo = 8u * (gl & 3u) + 4u * (gl >> 3);
-            const bool hi_dw = ((gl & 7u) >> 2) != 0;
-            for (uint32_t i = grp; i < S; i += 16) {
-                const uint32_t sl = q_slot[i];
-                const uint32_t* ex = reinterpret_cast<const uint32_t*>(P.ex_codes + (size_t)sl * exb);
-                float sacc = 0.0f;
-                if (ex_bits == 6) {
-#pragma unroll 4
-                    for (uint32_t t = 0; t < D / 16; ++t) {
-                        const uint32_t lo0 = ex[3 * t], lo1 = ex[3 * t + 1], hi = ex[3 * t + 2];
-                        const uint32_t lo = hi_dw ? lo1 : lo0;
-                        const uint32_t code = ((lo >> sh_lo) & 15u) | (((hi >> sh_hi) & 3u) << 4);
-                        sacc = fmaf((float)code, s_q[16 * t + gl], sacc);
-                    }
-                } else {
-#pragma unroll 4
-                    for (uint32_t t = 0; t < D / 16; ++t) {
-                        const uint32_t code = (ex[t] >> sh_hi) & 3u;
-                        sacc = fmaf((float)code, s_q[16 * t + gl], sacc);
-                    }
-                }
-                sacc = sacc + __shfl_xor(sacc, 8, 16);
-                sacc = sacc + __shfl_xor(sacc, 4, 16);
-                sacc = sacc + __shfl_xor(sacc, 2, 16);
-                sacc = sacc + __shfl_xor(sacc, 1, 16);
-                if (gl == 0) {
-                    float tt = qc.scale * q_ip[i];
-                    tt = tt + sacc;
-                    tt = tt + qc.kbx;
-                    const float a = P.f_add_ex[sl] + q_gadd[i];
-                    const float m = P.f_rescale_ex[sl] * tt;
-                    q_d[i] = a + m;
-                }
-            }
-            __syncthreads();
-        }
-
-        if (tid == 0) { // exact sequential replay of the reference's prune/push/pop loop
-            for (uint32_t i = 0; i < S; ++i) {
-                const float lb = q_lb[i];
-                const float distk = heap_len < top_k ? INFINITY : heap_d[0];
-                if (lb >= distk) { ++n_skip; continue; }
-                ++n_ext;
-                const float d = q_d[i];
-                if (!finite_f(d)) continue;
-                ++n_est;
-                const uint32_t sl = q_slot[i];
-                // BinaryHeap::push -> sift_up(0, old_len)
-                uint32_t pos = heap_len++;
-                const int kd = total_key(d);
-                while (pos > 0) {
-                    const uint32_t parent = (pos - 1) >> 1;
-                    if (kd <= total_key(heap_d[parent])) break;
-                    heap_d[pos] = heap_d[parent];
-                    heap_s[pos] = heap_s[parent];
-                    pos = parent;
-                }
-                heap_d[pos] = d;
-                heap_s[pos] = sl;
-                if (heap_len > top_k) { // BinaryHeap::pop: last -> root, sift_down_to_bottom, sift_up
-                    --heap_len;
-                    if (heap_len > 0) {
-                        const float ed = heap_d[heap_len];
-                        const uint32_t es = heap_s[heap_len];
-                        const uint32_t end = heap_len;
-                        uint32_t p = 0, child = 1;
-                        while (end >= 2 && child <= end - 2) {
-                            child += (total_key(heap_d[child]) <= total_key(heap_d[child + 1])) ? 1u : 0u;
-                            heap_d[p] = heap_d[child];
-                            heap_s[p] = heap_s[child];
-                            p = child;
-                            child = 2 * p + 1;
-                        }
-                        if (child == end - 1) {
-                            heap_d[p] = heap_d[child];
-                            heap_s[p] = heap_s[child];
-                            p = child;
-                        }
-                        const int ke = total_key(ed);
-                        while (p > 0) {
-                            const uint32_t parent = (p - 1) >> 1;
-                            if (ke <= total_key(heap_d[parent])) break;
-                            heap_d[p] = heap_d[parent];
-                            heap_s[p] = heap_s[parent];
-                            p = parent;
-                        }
-                        heap_d[p] = ed;
-                        heap_s[p] = es;
-                    }
-                }
-            }
-            s_T = heap_len < top_k ? INFINITY : heap_d[0];
-        }
-        __syncthreads();
-    }
-
-    // into_sorted_vec (src/ivf.rs:1874-1878) on thread 0, then parallel write-out
-    if (tid == 0) {
-        uint32_t end = heap_len;
-        while (end > 1) {
-            --end;
-            float td = heap_d[0]; heap_d[0] = heap_d[end]; heap_d[end] = td;
-            uint32_t ts = heap_s[0]; heap_s[0] = heap_s[end]; heap_s[end] = ts;
-            // sift_down_range(0, end)
-            const float ed = heap_d[0];
-            const uint32_t es = heap_s[0];
-            const int ke = total_key(ed);
-            uint32_t p = 0, child = 1;
-            bool placed = false;
-            while (end >= 2 && child <= end - 2) {
-                child += (total_key(heap_d[child]) <= total_key(heap_d[child + 1])) ? 1u : 0u;
-                if (ke >= total_key(heap_d[child])) { placed = true; break; }
-                heap_d[p] = heap_d[child];
-                heap_s[p] = heap_s[child];
-                p = child;
-                child = 2 * p + 1;
-            }
-            if (!placed && child == end - 1 && ke < total_key(heap_d[child])) {
-                heap_d[p] = heap_d[child];
-                heap_s[p] = heap_s[child];
-                p = child;
-            }
-            heap_d[p] = ed;
-            heap_s[p] = es;
-        }
-        s_len = heap_len;
-    }
-    if (P.diag && n_skip) atomicAdd(s_nskip, n_skip);
-    __syncthreads();
-    const uint32_t len = s_len;
-    for (uint32_t i = tid; i < top_k; i += kThreads) {
-        uint64_t id = ~0ull;
-        float sc = __int_as_float(0x7fc00000);
-        if (i < len) {
-            id = P.ids[heap_s[i]];
-            sc = P.metric == 0 ? heap_d[i] : -heap_d[i];
-        }
-        P.out_ids[(size_t)q * top_k + i] = id;
-        P.out_scores[(size_t)q * top_k + i] = sc;
-    }
-    if (tid == 0) {
-        P.out_counts[q] = len;
-        if (P.diag) {
-            P.diag[(size_t)q * 3 + 0] = n_est;
-            P.diag[(size_t)q * 3 + 1] = *s_nskip;
-            P.diag[(size_t)q * 3 + 2] = ex_bits ? n_ext : 0;
-        }
-    }
-}
-
 } // namespace rbq

@@ -16,6 +16,7 @@
 
 #include "rbq.h"
 #include "kernels.hpp"
+#include "scan.hpp"
 
 using namespace rbq;
 
@@ -117,6 +118,41 @@ inline uint8_t fastscan_byte(const uint8_t* packed, size_t col, uint32_t v) {
     return (uint8_t)((hi << 4) | lo);
 }
 
+// Reference packed ex code of one vector (src/simd.rs:2478-2541,2601-2695) -> device lane-major record:
+// lane l = dim % 16 holds codes of dims 16t+l as a little-endian bit string (ex bits each), stored
+// [j][lane][16 B] so that 16 lanes read 256 contiguous bytes per 16-byte load.
+void relayout_ex(const uint8_t* src, uint32_t D, uint32_t ex_bits, uint8_t* dst) {
+    const uint32_t w4 = ex_w4(D, ex_bits);
+    std::memset(dst, 0, (size_t)w4 * 256);
+    uint32_t* out = reinterpret_cast<uint32_t*>(dst);
+    for (uint32_t t = 0; t < D / 16; ++t) {
+        uint32_t codes[16];
+        if (ex_bits == 2) {
+            uint32_t w;
+            std::memcpy(&w, src + t * 4, 4);
+            for (uint32_t l = 0; l < 16; ++l) codes[l] = (w >> (8 * (l & 3) + 2 * (l >> 2))) & 3u;
+        } else { // 6
+            uint64_t lo;
+            uint32_t hi;
+            std::memcpy(&lo, src + t * 12, 8);
+            std::memcpy(&hi, src + t * 12 + 8, 4);
+            for (uint32_t l = 0; l < 16; ++l) {
+                const uint32_t low4 = l < 8 ? (uint32_t)((lo >> (8 * l)) & 15u) : (uint32_t)((lo >> (8 * (l - 8) + 4)) & 15u);
+                const uint32_t top2 = (hi >> (8 * (l & 3) + 2 * (l >> 2))) & 3u;
+                codes[l] = low4 | (top2 << 4);
+            }
+        }
+        const uint32_t bit = t * ex_bits, idx = bit >> 5, sh = bit & 31u;
+        for (uint32_t l = 0; l < 16; ++l) {
+            out[((idx >> 2) * 16 + l) * 4 + (idx & 3u)] |= codes[l] << sh;
+            if (sh + ex_bits > 32) {
+                const uint32_t i2 = idx + 1;
+                out[((i2 >> 2) * 16 + l) * 4 + (i2 & 3u)] |= codes[l] >> (32 - sh);
+            }
+        }
+    }
+}
+
 // One reference batch record -> one device block: lane-major code granules + the three factor rows.
 void relayout_block(const uint8_t* rec, uint32_t D, uint32_t Dc, uint8_t* dst) {
     const size_t dim_bytes = D / 8, G16 = Dc >> 7;
@@ -184,6 +220,7 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
 
     const uint32_t D = ix->D, Dc = ix->Dc;
     const size_t ref_stride = (size_t)D * 4 + 384, dev_stride = (size_t)Dc * 4 + 384, exb = (size_t)D * ix->ex_bits / 8;
+    const size_t exd = ex_bytes_dev(D, ix->ex_bits);
     std::vector<uint32_t> gb0(ix->n_lists), ln(ix->n_lists);
     uint64_t nblocks = 0, nvec = 0;
     for (uint64_t c = 0; c < ix->n_lists; ++c) {
@@ -205,7 +242,7 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     std::vector<float> cent((size_t)ix->n_lists * D);
     std::vector<uint8_t> blocks(nblocks * dev_stride);
     std::vector<uint64_t> ids(nblocks * 32, ~0ull);
-    std::vector<uint8_t> ex(exb ? nblocks * 32 * exb : 0);
+    std::vector<uint8_t> ex(exd ? nblocks * 32 * exd + 256 : 0);
     std::vector<float> fa(ix->ex_bits ? nblocks * 32 : 0), fr(ix->ex_bits ? nblocks * 32 : 0);
     for (uint64_t c = 0; c < ix->n_lists; ++c) {
         const rbq_list_view& L = lists[c];
@@ -217,7 +254,7 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
         if (L.n) {
             std::memcpy(&ids[s0], L.ids, L.n * 8);
             if (ix->ex_bits) {
-                std::memcpy(&ex[s0 * exb], L.ex_codes, L.n * exb);
+                for (uint64_t v = 0; v < L.n; ++v) relayout_ex(L.ex_codes + v * exb, D, ix->ex_bits, &ex[(s0 + v) * exd]);
                 std::memcpy(&fa[s0], L.f_add_ex, L.n * 4);
                 std::memcpy(&fr[s0], L.f_rescale_ex, L.n * 4);
             }
@@ -274,12 +311,21 @@ struct ProfScope {
     }
 };
 
+template <int DT, int EX>
+hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
+    return hipGetLastError();
+}
 template <int DT>
 hipError_t launch_scan(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_scan<DT>, dim3(nq), dim3(kThreads), lds, s, P);
-    return hipGetLastError();
+    if (DT == 0) return launch_scan_t<0, 0>(P, nq, lds, s);
+    switch (P.ex_bits) {
+        case 0: return launch_scan_t<DT, 0>(P, nq, lds, s);
+        case 2: return launch_scan_t<DT, 2>(P, nq, lds, s);
+        default: return launch_scan_t<DT, 6>(P, nq, lds, s);
+    }
 }
 
 // Core: everything on device pointers, enqueued on `stream`. Workspace buffers come from `w`.
@@ -344,7 +390,7 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
         P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
         P.D = D; P.Dc = Dc; P.nprobe = nprobe; P.top_k = top_k; P.metric = ix->metric; P.ex_bits = ix->ex_bits;
-        const size_t lds = (size_t)Dc * 4 + (size_t)D * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 20 + kTileBlocks * 4 + 16;
+        const size_t lds = scan_lds_bytes(Dc, D, top_k);
         hipError_t e;
         if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
         else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream);

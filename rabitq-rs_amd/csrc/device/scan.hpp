@@ -1,0 +1,629 @@
+// scan.hpp — k_scan, the roofline kernel of the IVF+RaBitQ query path (gfx950, wave64).
+//
+// Reference semantics: search_cluster_v2_batched (src/ivf.rs:1901-2129) over the probed lists of one
+// query, i.e. accumulate_batch (src/simd.rs:972-1184) + compute_batch_distances_u16 (:2090-2140) +
+// lower-bound pruning + ip_packed_ex{2,6}_f32 (:1835-1915) + BinaryHeap top-k (src/ivf.rs:904-931).
+//
+// One workgroup = one query, with fixed wave roles:
+//   waves 0..NS-1 "scanners": stream the query's block work list, 2*NS blocks (64*NS candidates) per tile,
+//             lane = vector; the codes of tile t+1 are prefetched into registers while tile t is looked up
+//             in LDS; survivors (lb < T) are published (mask, lb, ip, est, slot) to a double-buffered LDS queue.
+//   wave NS   "replay wave": compacts the previous tile's survivors in stream order, refines them (16 lanes
+//             per survivor over a lane-major copy of the ex codes) and replays them through the reference's
+//             exact prune/push/pop loop — a Rust-BinaryHeap-faithful heap held in the wave's registers
+//             (v_readlane/v_writelane) — while the scanners are already on the next tile; publishes T.
+// Exactness: scanners prune with a STALE threshold T.  T only ever shrinks, so `lb >= T_stale` implies the
+// reference (whose threshold at that moment is <= T_stale) skipped the candidate too; everything else is
+// re-tested by the replay wave against the true running threshold, in stream order.  ids therefore equal
+// the sequential CPU path bit for bit.  Tiles with more than kLightMax survivors (the first probed lists,
+// where T is still loose) run synchronously: every wave refines and the scanners wait for the fresh T.
+#pragma once
+#include "kernels.hpp"
+
+namespace rbq {
+
+struct ScanParams {
+    const uint8_t* blocks;   // [n_blocks][4Dc + 384]: lane-major sign codes | f_add[32] | f_rescale[32] | f_error[32]
+    const uint64_t* ids;     // [n_blocks*32]
+    const uint8_t* ex_codes; // [n_blocks*32][ex_bytes_dev]: lane-major ex codes, see ex_w4()
+    const float* f_add_ex;   // [n_blocks*32]
+    const float* f_rescale_ex;
+    const uint8_t* lut;      // [nq][4Dc] (pair-swapped codebook order); Dc = D rounded up to x64
+    const float* rot;        // [nq][D]
+    const QueryConsts* consts;
+    const ProbeInfo* probe;  // [nq][nprobe]
+    const WorkItem* wl;      // [nq][wl_stride]
+    const uint32_t* nstream; // [nq]
+    const uint32_t* filter;  // dense bitset or null
+    uint64_t filter_nbits;
+    uint64_t wl_stride;
+    uint64_t* out_ids;
+    float* out_scores;
+    uint32_t* out_counts;
+    unsigned long long* diag; // [nq][3] or null
+    uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
+};
+
+#ifndef RBQ_SCAN_WAVES
+#define RBQ_SCAN_WAVES 4    // launch-bounds occupancy target (waves per SIMD)
+#endif
+#ifndef RBQ_NSCAN
+#define RBQ_NSCAN 3         // scanner waves per workgroup (3 + replay wave = 256 threads: 4 workgroups per CU)
+#endif
+#ifndef RBQ_LIGHT_MAX
+#define RBQ_LIGHT_MAX 12
+#endif
+#ifndef RBQ_PIN_MODE
+#define RBQ_PIN_MODE 1
+#endif
+constexpr int kNScan = RBQ_NSCAN;
+constexpr int kScanThreads = (kNScan + 1) * 64; // scanner waves + 1 replay wave
+constexpr int kTileBlocks = 2 * kNScan;         // 32-vector blocks per tile (one per scanner half-wave)
+constexpr int kTileCand = kTileBlocks * 32;     // candidates per tile
+constexpr uint32_t kLightMax = RBQ_LIGHT_MAX;   // tiles with more survivors than this run synchronously
+
+// Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 x 16 B, stored [j][lane][16 B];
+// lane l holds the codes of dims 16t+l (t = 0..D/16-1) as a little-endian bit string, ex bits each.
+__host__ __device__ inline uint32_t ex_w4(uint32_t D, uint32_t ex_bits) { // 16-byte units per lane
+    return ex_bits ? ((D / 16) * ex_bits + 127u) / 128u : 0u;
+}
+__host__ __device__ inline uint32_t ex_bytes_dev(uint32_t D, uint32_t ex_bits) { return ex_w4(D, ex_bits) * 256u; }
+
+// LUT pointer in the LDS address space, formed from a plain integer offset.  A pointer derived from the
+// `extern __shared__` symbol carries a link-time relocation that hipcc adds with one v_add_u32 PER LOOKUP
+// (`v_add_u32 v, 0, v` after linking); an integer-derived address lets the codebook offset fold into the
+// ds_read_u8 immediate.  k_scan keeps its LUT at LDS byte 0 and traps if the dynamic region is not there.
+typedef const __attribute__((address_space(3))) uint8_t* lds_lut_ptr;
+
+// 8 nibble lookups of one little-endian code dword; table p+16*m serves nibble m.  The empty asm pins the
+// running sum so the integer adds are not re-associated into one end-of-block reduction (which made hipcc
+// keep, and spill, every ds_read result).
+__device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, lds_lut_ptr p) {
+    uint32_t s = p[x & 15u];
+    s += p[16 + ((x >> 4) & 15u)];
+    s += p[32 + ((x >> 8) & 15u)];
+    s += p[48 + ((x >> 12) & 15u)];
+    s += p[64 + ((x >> 16) & 15u)];
+    s += p[80 + ((x >> 20) & 15u)];
+    s += p[96 + ((x >> 24) & 15u)];
+    s += p[112 + (x >> 28)];
+    acc += s;
+#if RBQ_PIN_MODE == 0
+    asm volatile("" : "+v"(acc));
+#elif RBQ_PIN_MODE == 1
+    asm("" : "+v"(acc));
+#endif
+}
+
+// Register image of one vector's sign code (lane l32 of a block): Dc/128 16-byte granules + optional 8-byte tail.
+template <int DT>
+struct CodeRegs {
+    static constexpr int G = (DT >> 7) ? (DT >> 7) : 1;
+    uint4 x[G];
+    uint2 tail;
+};
+
+template <int DT>
+__device__ __forceinline__ void load_codes(CodeRegs<DT>& c, const uint8_t* __restrict__ blk, uint32_t l32) {
+    const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
+#pragma unroll
+    for (int g = 0; g < (DT >> 7); ++g) c.x[g] = cp[g * 32];
+    if (DT & 64) c.tail = *(reinterpret_cast<const uint2*>(blk + (DT >> 7) * 512) + l32);
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t lookup_codes(const CodeRegs<DT>& c, lds_lut_ptr lut) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int g = 0; g < (DT >> 7); ++g) {
+        look8(acc, c.x[g].x, lut + g * 512);
+        look8(acc, c.x[g].y, lut + g * 512 + 128);
+        look8(acc, c.x[g].z, lut + g * 512 + 256);
+        look8(acc, c.x[g].w, lut + g * 512 + 384);
+    }
+    if (DT & 64) {
+        look8(acc, c.tail.x, lut + (DT >> 7) * 512);
+        look8(acc, c.tail.y, lut + (DT >> 7) * 512 + 128);
+    }
+    return acc;
+}
+
+// generic (runtime Dc) path: no register prefetch
+__device__ __forceinline__ uint32_t accumulate_block_rt(const uint8_t* __restrict__ blk, lds_lut_ptr lut,
+                                                        uint32_t l32, uint32_t Dc) {
+    const uint32_t G16 = Dc >> 7;
+    const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
+    uint32_t acc = 0;
+    for (uint32_t g = 0; g < G16; ++g) {
+        uint4 x = cp[g * 32];
+        look8(acc, x.x, lut + g * 512);
+        look8(acc, x.y, lut + g * 512 + 128);
+        look8(acc, x.z, lut + g * 512 + 256);
+        look8(acc, x.w, lut + g * 512 + 384);
+    }
+    if (Dc & 64u) {
+        uint2 y = *(reinterpret_cast<const uint2*>(blk + G16 * 512) + l32);
+        look8(acc, y.x, lut + G16 * 512);
+        look8(acc, y.y, lut + G16 * 512 + 128);
+    }
+    return acc;
+}
+
+// workgroup barrier that only drains LDS traffic: prefetched global loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- Rust std BinaryHeap<HeapEntry> on LDS arrays (max-heap on total_cmp(distance)) -----------------------
+struct LdsHeap {
+    float* d;
+    uint32_t* s;
+    uint32_t len;
+    __device__ __forceinline__ void sift_up(uint32_t pos, float ed, uint32_t es) {
+        const int ke = total_key(ed);
+        while (pos > 0) {
+            const uint32_t parent = (pos - 1) >> 1;
+            if (ke <= total_key(d[parent])) break;
+            d[pos] = d[parent];
+            s[pos] = s[parent];
+            pos = parent;
+        }
+        d[pos] = ed;
+        s[pos] = es;
+    }
+    __device__ __forceinline__ void push(float dist, uint32_t slot) { sift_up(len++, dist, slot); }
+    __device__ __forceinline__ void pop() { // last -> root, sift_down_to_bottom(0), sift_up
+        --len;
+        if (len == 0) return;
+        const float ed = d[len];
+        const uint32_t es = s[len];
+        const uint32_t end = len;
+        uint32_t p = 0, child = 1;
+        while (end >= 2 && child <= end - 2) {
+            child += (total_key(d[child]) <= total_key(d[child + 1])) ? 1u : 0u;
+            d[p] = d[child];
+            s[p] = s[child];
+            p = child;
+            child = 2 * p + 1;
+        }
+        if (child == end - 1) {
+            d[p] = d[child];
+            s[p] = s[child];
+            p = child;
+        }
+        sift_up(p, ed, es);
+    }
+    __device__ __forceinline__ void into_sorted() { // into_sorted_vec: swap(0,end); sift_down_range(0,end)
+        uint32_t end = len;
+        while (end > 1) {
+            --end;
+            const float ed = d[end];
+            const uint32_t es = s[end];
+            d[end] = d[0];
+            s[end] = s[0];
+            const int ke = total_key(ed);
+            uint32_t p = 0, child = 1;
+            bool placed = false;
+            while (end >= 2 && child <= end - 2) {
+                child += (total_key(d[child]) <= total_key(d[child + 1])) ? 1u : 0u;
+                if (ke >= total_key(d[child])) { placed = true; break; }
+                d[p] = d[child];
+                s[p] = s[child];
+                p = child;
+                child = 2 * p + 1;
+            }
+            if (!placed && child == end - 1 && ke < total_key(d[child])) {
+                d[p] = d[child];
+                s[p] = s[child];
+                p = child;
+            }
+            d[p] = ed;
+            s[p] = es;
+        }
+    }
+};
+
+// ---- ex-code refine: sum_t code[16t+gl] * q[16t+gl] for one 16-lane group, AVX-512 lane order --------------
+// (ip_packed_ex{2,6}_f32, src/simd.rs:1835-1915: one fused multiply-add per 16-dim step per lane, then the
+// _mm512_reduce_add_ps halving tree.)  The vector's lane-major ex record is loaded with W4 16-byte loads per
+// lane and decoded from registers.
+template <int DT, int EX>
+struct ExRegs {
+    static constexpr int W4 = ((DT / 16) * EX + 127) / 128;
+    uint32_t w[W4 * 4 + 1];
+};
+template <int DT, int EX>
+__device__ __forceinline__ void ex_load(ExRegs<DT, EX>& r, const uint8_t* __restrict__ ex, uint32_t gl) {
+    const uint4* p = reinterpret_cast<const uint4*>(ex) + gl;
+#pragma unroll
+    for (int j = 0; j < ExRegs<DT, EX>::W4; ++j) {
+        const uint4 v = p[j * 16];
+        r.w[4 * j] = v.x; r.w[4 * j + 1] = v.y; r.w[4 * j + 2] = v.z; r.w[4 * j + 3] = v.w;
+    }
+    r.w[ExRegs<DT, EX>::W4 * 4] = 0;
+}
+template <int DT, int EX>
+__device__ __forceinline__ float ex_dot(const ExRegs<DT, EX>& r, const float* s_q, uint32_t gl) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < DT / 16; ++t) {
+        constexpr uint32_t mask = (1u << EX) - 1u;
+        const int bit = t * EX, idx = bit >> 5, sh = bit & 31;
+        uint32_t code;
+        if (sh + EX <= 32) code = (r.w[idx] >> sh) & mask;
+        else code = ((r.w[idx] >> sh) | (r.w[idx + 1] << (32 - sh))) & mask;
+        sacc = fmaf((float)code, s_q[16 * t + gl], sacc);
+    }
+    return sacc;
+}
+// runtime-shape fallback (any D, ex in {2,6})
+__device__ inline float ex_dot_lane_rt(const uint8_t* __restrict__ ex, const float* s_q, uint32_t gl, uint32_t D,
+                                       uint32_t ex_bits) {
+    const uint32_t* base = reinterpret_cast<const uint32_t*>(ex);
+    const uint32_t mask = (1u << ex_bits) - 1u;
+    float sacc = 0.0f;
+    for (uint32_t t = 0; t < D / 16; ++t) {
+        const uint32_t bit = t * ex_bits, idx = bit >> 5, sh = bit & 31u;
+        // dword idx of lane gl lives at unit j = idx/4: [j][lane][4 dwords]
+        uint32_t lo = base[((idx >> 2) * 16 + gl) * 4 + (idx & 3u)];
+        uint32_t code = lo >> sh;
+        if (sh + ex_bits > 32) {
+            const uint32_t i2 = idx + 1;
+            code |= base[((i2 >> 2) * 16 + gl) * 4 + (i2 & 3u)] << (32 - sh);
+        }
+        sacc = fmaf((float)(code & mask), s_q[16 * t + gl], sacc);
+    }
+    return sacc;
+}
+__device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_add_ps halving tree
+    sacc = sacc + __shfl_xor(sacc, 8, 16);
+    sacc = sacc + __shfl_xor(sacc, 4, 16);
+    sacc = sacc + __shfl_xor(sacc, 2, 16);
+    sacc = sacc + __shfl_xor(sacc, 1, 16);
+    return sacc;
+}
+
+// ---- the same BinaryHeap held in the replay wave's registers: entry i lives in lane i (top_k <= 63) --------
+// All indices and values are wave-uniform, so every access is a v_readlane/v_writelane (a few cycles)
+// instead of a dependent LDS round trip.
+struct RegHeap {
+    int hd;      // distance bits of entry `lane`
+    uint32_t hs; // slot of entry `lane`
+    uint32_t len;
+    __device__ __forceinline__ int d_at(uint32_t i) const { return __builtin_amdgcn_readlane(hd, (int)i); }
+    __device__ __forceinline__ uint32_t s_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)hs, (int)i); }
+    __device__ __forceinline__ void set(uint32_t i, int d, uint32_t s) { // v_writelane as compare+select
+        const bool me = (__lane_id() == i);
+        hd = me ? d : hd;
+        hs = me ? s : hs;
+    }
+    static __device__ __forceinline__ int key(int bits) { return bits ^ (int)(((uint32_t)(bits >> 31)) >> 1); }
+    __device__ __forceinline__ void sift_up(uint32_t pos, int ed, uint32_t es) {
+        const int ke = key(ed);
+        while (pos > 0) {
+            const uint32_t parent = (pos - 1) >> 1;
+            const int pd = d_at(parent);
+            if (ke <= key(pd)) break;
+            set(pos, pd, s_at(parent));
+            pos = parent;
+        }
+        set(pos, ed, es);
+    }
+    __device__ __forceinline__ void push(int dbits, uint32_t slot) { sift_up(len++, dbits, slot); }
+    __device__ __forceinline__ void pop() {
+        --len;
+        if (len == 0) return;
+        const int ed = d_at(len);
+        const uint32_t es = s_at(len);
+        const uint32_t end = len;
+        uint32_t p = 0, child = 1;
+        while (end >= 2 && child <= end - 2) {
+            const int c0 = d_at(child), c1 = d_at(child + 1);
+            const bool right = key(c0) <= key(c1);
+            child += right ? 1u : 0u;
+            set(p, right ? c1 : c0, s_at(child));
+            p = child;
+            child = 2 * p + 1;
+        }
+        if (child == end - 1) {
+            set(p, d_at(child), s_at(child));
+            p = child;
+        }
+        sift_up(p, ed, es);
+    }
+};
+
+// LDS carve-up (dynamic only, LUT at byte 0):
+//   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
+//   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | T, len, nskip, pad
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t top_k) {
+    return (size_t)Dc * 4 + (size_t)D * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
+           2 * kTileBlocks * 4 + 16;
+}
+
+// EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
+template <int DT, int EX>
+__global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParams P) {
+    extern __shared__ __align__(16) unsigned char smraw[];
+    const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
+    const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
+    uint8_t* s_lut = smraw;
+    float* s_q = reinterpret_cast<float*>(smraw + (size_t)Dc * 4);
+    float* heap_d = s_q + D;
+    uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
+    uint32_t* q_slot = heap_s + (P.top_k + 1);                      // [2][kTileCand]
+    float* q_lb = reinterpret_cast<float*>(q_slot + 2 * kTileCand);
+    float* q_ip = q_lb + 2 * kTileCand;
+    float* q_gadd = q_ip + 2 * kTileCand;
+    float* q_d = q_gadd + 2 * kTileCand;
+    uint32_t* s_list = reinterpret_cast<uint32_t*>(q_d + 2 * kTileCand); // [kTileCand] survivor positions, stream order
+    uint32_t* s_mask = s_list + kTileCand;                                // [2][kTileBlocks]
+    // no static __shared__ in this kernel: the dynamic region must start at LDS address 0 (see lds_lut_ptr)
+    float& s_T = *reinterpret_cast<float*>(s_mask + 2 * kTileBlocks);
+    uint32_t& s_len = *(s_mask + 2 * kTileBlocks + 1);
+    uint32_t* s_nskip = s_mask + 2 * kTileBlocks + 2;
+
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u, half = lane >> 5, l32 = lane & 31u;
+    const uint32_t hw = tid >> 5; // half-wave index; scanners own blocks 0..kTileBlocks-1 of a tile
+    const bool scanner = wave < (uint32_t)kNScan;
+    const lds_lut_ptr lut0 = (lds_lut_ptr)(uint32_t)0; // == s_lut
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smraw != 0u) __builtin_trap();
+    const uint32_t top_k = P.top_k;
+    const uint32_t ex_bits = DT ? (uint32_t)EX : P.ex_bits;
+    const size_t stride = (size_t)Dc * 4 + 384;
+    const size_t exb = ex_bytes_dev(D, ex_bits);
+
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
+        uint4* dst = reinterpret_cast<uint4*>(s_lut);
+        for (uint32_t i = tid; i < Dc / 4; i += kScanThreads) dst[i] = src[i];
+        for (uint32_t i = tid; i < D; i += kScanThreads) s_q[i] = P.rot[(size_t)q * D + i];
+        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; }
+    }
+    const QueryConsts qc = P.consts[q];
+    const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
+    const WorkItem* wl = P.wl + (size_t)q * P.wl_stride;
+    const uint32_t ns = P.nstream[q];
+    const uint32_t ntiles = (ns + kTileBlocks - 1) / kTileBlocks;
+    __syncthreads();
+
+    uint32_t n_skip = 0, n_ext = 0, n_est = 0; // n_skip: every thread; n_ext/n_est: replay wave (uniform)
+
+    // refine survivors i = g0, g0+gstep, ... of tile buffer `buf`; 16 lanes per survivor
+    auto refine = [&](uint32_t buf, uint32_t S, uint32_t g0, uint32_t gstep) {
+        const uint32_t gl = tid & 15u;
+        for (uint32_t i = g0; i < S; i += gstep) {
+            const uint32_t e = buf * kTileCand + s_list[i];
+            const uint32_t sl = q_slot[e];
+            const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
+            float sacc;
+            if (DT) {
+                ExRegs<DT ? DT : 16, (DT && EX) ? EX : 2> r;
+                ex_load(r, ex, gl);
+                sacc = ex_dot(r, s_q, gl);
+            } else {
+                sacc = ex_dot_lane_rt(ex, s_q, gl, D, ex_bits);
+            }
+            sacc = group16_reduce(sacc);
+            if (gl == 0) {
+                float tt2 = qc.scale * q_ip[e];
+                tt2 = tt2 + sacc;
+                tt2 = tt2 + qc.kbx;
+                const float a = P.f_add_ex[sl] + q_gadd[e];
+                const float m = P.f_rescale_ex[sl] * tt2;
+                q_d[e] = a + m;
+            }
+        }
+    };
+
+#ifdef RBQ_STAMPS
+    unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0;
+    uint32_t st_nheavy = 0, st_surv = 0;
+#define STAMP(x) x = __builtin_amdgcn_s_memtime()
+    unsigned long long st_a, st_b;
+#else
+#define STAMP(x)
+#endif
+    if (scanner) {
+        // ------------------------------------------------------------------ scanner waves
+        auto load_wi = [&](uint32_t t) -> WorkItem {
+            const uint32_t s = t * kTileBlocks + hw;
+            WorkItem w;
+            w.gblock = 0; w.rank_nvalid = 0; // nvalid 0 -> every lane invalid; block 0 keeps the loads in range
+            if (s < ns) w = wl[s];
+            return w;
+        };
+        WorkItem wi_c = load_wi(0), wi_n = load_wi(1);
+        CodeRegs<DT> cc, cn;
+        if (DT) load_codes<DT>(cc, P.blocks + (size_t)wi_c.gblock * stride, l32);
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const uint32_t buf = t & 1u;
+            const uint8_t* blk = P.blocks + (size_t)wi_c.gblock * stride;
+            // issue everything the next tile needs before touching LDS
+            if (DT) load_codes<DT>(cn, P.blocks + (size_t)wi_n.gblock * stride, l32);
+            const WorkItem wi_nn = load_wi(t + 2);
+            const uint32_t rank = wi_c.rank_nvalid >> 6, nvalid = wi_c.rank_nvalid & 63u;
+            const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
+            const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
+            const ProbeInfo pi = probe[rank];
+            const float T = s_T;
+            STAMP(st_a);
+            const uint32_t accu = (DT ? lookup_codes<DT>(cc, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
+#ifdef RBQ_STAMPS
+            asm volatile("" :: "v"(accu));
+            STAMP(st_b); st_look += st_b - st_a;
+#endif
+            // compute_batch_distances_u16 (AVX2 body): only the first op is fused
+            const float ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
+            const float tt = ip + qc.k1x;
+            const float rs = f_rescale * tt;
+            float est = f_add + pi.g_add;
+            est = est + rs;
+            const float er = f_error * pi.g_err;
+            float lb = est - er;
+            const uint32_t slot = wi_c.gblock * 32u + l32;
+            bool valid = l32 < nvalid;
+            if (valid && P.filter) {
+                const uint32_t id32 = (uint32_t)P.ids[slot];
+                valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
+            }
+            if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(pi.dotqc + qc.qnorm);
+            const bool surv = valid && (lb < T);
+            if (valid && !surv) ++n_skip;
+            const unsigned long long bal = __ballot(surv);
+            const uint32_t mask32 = (uint32_t)(bal >> (half * 32));
+            if (l32 == 0) s_mask[buf * kTileBlocks + hw] = mask32;
+            if (surv) {
+                const uint32_t e = buf * kTileCand + hw * 32u + l32;
+                q_slot[e] = slot;
+                q_lb[e] = lb;
+                q_ip[e] = ip;
+                q_gadd[e] = pi.g_add;
+                q_d[e] = est;
+            }
+            STAMP(st_a);
+            lds_barrier(); // A: tile t is published to the replay wave
+#ifdef RBQ_STAMPS
+            STAMP(st_b); st_waitA += st_b - st_a;
+#endif
+            uint32_t S = 0;
+#pragma unroll
+            for (int j = 0; j < kTileBlocks; ++j) S += __popc(s_mask[buf * kTileBlocks + j]);
+#ifdef RBQ_STAMPS
+            st_surv += S;
+#endif
+            if (S > kLightMax) { // synchronous tile: help refining, then wait for the fresh threshold
+                STAMP(st_a);
+                lds_barrier();   // B: survivor list compacted
+                if (ex_bits) refine(buf, S, tid >> 4, kScanThreads / 16);
+                lds_barrier();   // C: refined distances visible
+                lds_barrier();   // D: replay done, s_T updated
+#ifdef RBQ_STAMPS
+                STAMP(st_b); st_heavy += st_b - st_a; ++st_nheavy;
+#endif
+            }
+            wi_c = wi_n;
+            wi_n = wi_nn;
+            if (DT) cc = cn;
+        }
+        lds_barrier(); // F: replay wave has consumed the last tile
+    } else {
+        // ------------------------------------------------------------------ replay wave (uniform control flow)
+        const bool reg_heap = top_k < 64;
+        RegHeap rh{0, 0u, 0u};
+        LdsHeap lh{heap_d, heap_s, 0};
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const uint32_t buf = t & 1u;
+            lds_barrier(); // A
+            // compaction in stream order: block by block, lane order within the block
+            for (uint32_t b = half; b < (uint32_t)kTileBlocks; b += 2) {
+                uint32_t base = 0;
+                for (uint32_t j = 0; j < b; ++j) base += __popc(s_mask[buf * kTileBlocks + j]);
+                const uint32_t m = s_mask[buf * kTileBlocks + b];
+                if ((m >> l32) & 1u) s_list[base + __popc(m & ((1u << l32) - 1u))] = b * 32u + l32;
+            }
+            uint32_t S = 0;
+#pragma unroll
+            for (int j = 0; j < kTileBlocks; ++j) S += __popc(s_mask[buf * kTileBlocks + j]);
+            S = __builtin_amdgcn_readfirstlane(S);
+            const bool heavy = S > kLightMax;
+            if (heavy) {
+                lds_barrier(); // B
+                if (ex_bits) refine(buf, S, tid >> 4, kScanThreads / 16);
+                lds_barrier(); // C
+            } else if (S) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ex_bits) refine(buf, S, lane >> 4, 4);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            // exact sequential replay of the reference's prune/push/pop loop, in stream order
+            if (reg_heap) {
+                for (uint32_t c0 = 0; c0 < S; c0 += 64) {
+                    const uint32_t cnt = S - c0 < 64 ? S - c0 : 64;
+                    int v_lb = 0, v_d = 0;
+                    uint32_t v_s = 0;
+                    if (lane < cnt) { // lane i stages survivor c0+i
+                        const uint32_t e = buf * kTileCand + s_list[c0 + lane];
+                        v_lb = __float_as_int(q_lb[e]);
+                        v_d = __float_as_int(q_d[e]);
+                        v_s = q_slot[e];
+                    }
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)i));
+                        const float distk = rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0));
+                        if (lb >= distk) { ++n_skip; continue; }
+                        ++n_ext;
+                        const int dbits = __builtin_amdgcn_readlane(v_d, (int)i);
+                        if (!finite_f(__int_as_float(dbits))) continue;
+                        ++n_est;
+                        rh.push(dbits, (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)i));
+                        if (rh.len > top_k) rh.pop();
+                    }
+                }
+                if (lane == 0) s_T = rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0));
+            } else if (lane == 0) {
+                for (uint32_t i = 0; i < S; ++i) {
+                    const uint32_t e = buf * kTileCand + s_list[i];
+                    const float lb = q_lb[e];
+                    const float distk = lh.len < top_k ? INFINITY : heap_d[0];
+                    if (lb >= distk) { ++n_skip; continue; }
+                    ++n_ext;
+                    const float d = q_d[e];
+                    if (!finite_f(d)) continue;
+                    ++n_est;
+                    lh.push(d, q_slot[e]);
+                    if (lh.len > top_k) lh.pop();
+                }
+                s_T = lh.len < top_k ? INFINITY : heap_d[0];
+            }
+            if (heavy) lds_barrier(); // D
+        }
+        if (reg_heap) { // spill the register heap to LDS for the final heap-sort
+            if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
+            lh.len = rh.len;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (lane == 0) {
+            lh.into_sorted();
+            s_len = lh.len;
+        }
+        lds_barrier(); // F
+        if (lane != 0) { n_skip = 0; n_ext = 0; n_est = 0; } // uniform counters: report them once
+    }
+
+    if (P.diag && n_skip) atomicAdd(s_nskip, n_skip);
+    __syncthreads();
+    const uint32_t len = s_len;
+    for (uint32_t i = tid; i < top_k; i += kScanThreads) {
+        uint64_t id = ~0ull;
+        float sc = __int_as_float(0x7fc00000);
+        if (i < len) {
+            id = P.ids[heap_s[i]];
+            sc = P.metric == 0 ? heap_d[i] : -heap_d[i];
+        }
+        P.out_ids[(size_t)q * top_k + i] = id;
+        P.out_scores[(size_t)q * top_k + i] = sc;
+    }
+#ifdef RBQ_STAMPS
+    if (tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
+        st_total = __builtin_amdgcn_s_memtime() - st_total;
+        P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | (st_waitA << 32);
+        P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | ((unsigned long long)st_nheavy << 32);
+        P.diag[(size_t)q * 3 + 2] = (unsigned long long)st_surv | (st_look << 32);
+    }
+    if (wave == (uint32_t)kNScan && lane == 0) { P.out_counts[q] = len; }
+    if (false) {
+#else
+    if (wave == (uint32_t)kNScan && lane == 0) {
+#endif
+        P.out_counts[q] = len;
+        if (P.diag) {
+            P.diag[(size_t)q * 3 + 0] = n_est;
+            P.diag[(size_t)q * 3 + 1] = *s_nskip;
+            P.diag[(size_t)q * 3 + 2] = ex_bits ? n_ext : 0;
+        }
+    }
+}
+
+} // namespace rbq

@@ -1,0 +1,23 @@
+"""Diagnostic: run one batch through a -DRBQ_STAMPS build and print where scanner wave 0 spends its cycles."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+import rabitq_rs_amd as rq
+a = bench.parse()
+dev = torch.device("cuda", 0)
+x = bench.mixture(torch, dev, a.n, a.dim, a.nlist, 20260105, False)
+cent, assign = bench.kmeans_gpu(torch, x, a.nlist, 6, 20260103)
+built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits, 0, 1, 20260104, True)
+idx = rq.IvfRabitqIndex.from_built(built)
+q = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).cpu().numpy()
+for _ in range(2):
+    ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
+d = diag.astype(np.uint64)
+heavy = (d[:, 0] & 0xffffffff).astype(np.float64); waitA = (d[:, 0] >> 32).astype(np.float64)
+total = (d[:, 1] & 0xffffffff).astype(np.float64); nheavy = (d[:, 1] >> 32).astype(np.float64)
+surv = (d[:, 2] & 0xffffffff).astype(np.float64); look = (d[:, 2] >> 32).astype(np.float64)
+print("per-query means (cycles of s_memtime): total %.0f  lookups %.0f (%.0f%%)  waitA %.0f (%.0f%%)  heavy %.0f (%.0f%%)" % (
+    total.mean(), look.mean(), 100 * look.mean() / total.mean(), waitA.mean(), 100 * waitA.mean() / total.mean(), heavy.mean(), 100 * heavy.mean() / total.mean()))
+print("heavy tiles/query %.1f  survivors/query %.0f  total p50 %.0f p99 %.0f max %.0f" % (nheavy.mean(), surv.mean(), np.percentile(total, 50), np.percentile(total, 99), total.max()))
