@@ -22,7 +22,8 @@ namespace rbq {
 constexpr int kThreads = 256;
 
 struct QueryConsts {
-    float delta, sum_vl, k1x, kbx, scale, qnorm, sum_q, pad;
+    float delta, sum_vl, k1x, kbx, scale, qnorm;
+    float amin, amax; // sum over codebooks of the smallest / largest u8 entry: accu of ANY code lies in [amin, amax]
 };
 struct ProbeInfo {
     float g_add, g_err, dotqc;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
     float* x = sm;         // [D]
     float* y = sm + D;     // [D] (matrix rotator input)
     __shared__ int s_kmin, s_kmax;
+    __shared__ unsigned int s_amin, s_amax;
     __shared__ float s_sum, s_n2;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const float* qin = queries + (size_t)q * dim;
@@ -130,6 +132,8 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         s_sum = s;
         s_kmin = 0x7fffffff;
         s_kmax = (int)0x80000000;
+        s_amin = 0;
+        s_amax = 0;
     }
     if (tid == 64) {
         float n2 = -0.0f;
@@ -185,15 +189,23 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         uint32_t c = tid + u * kThreads;
         if (c < ncb) {
             uint32_t w[4] = {0, 0, 0, 0};
+            uint32_t emin = 255, emax = 0;
             if (delta > 0.0f) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     float v = roundf((l[u][j] - vl) / delta);
                     v = v >= 0.0f ? v : 0.0f; // also maps NaN -> 0 like `as u8`
                     v = v > 255.0f ? 255.0f : v;
-                    w[j >> 2] |= (uint32_t)v << (8 * (j & 3));
+                    const uint32_t e = (uint32_t)v;
+                    emin = e < emin ? e : emin;
+                    emax = e > emax ? e : emax;
+                    w[j >> 2] |= e << (8 * (j & 3));
                 }
+            } else {
+                emin = 0;
             }
+            atomicAdd(&s_amin, emin);
+            atomicAdd(&s_amax, emax);
             // device LUT order: adjacent codebooks swapped (position p holds codebook p^1) so that
             // nibble m of a little-endian code dword indexes table (8*dword + m) directly.
             uint4* dst = reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16);
@@ -203,17 +215,18 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
             *dst = make_uint4(0, 0, 0, 0);
         }
     }
+    __syncthreads();
     if (tid == 0) {
         QueryConsts qc;
+        qc.amin = (float)s_amin;
+        qc.amax = (float)s_amax;
         qc.delta = delta;
         qc.sum_vl = vl * (float)(D / 4);
-        qc.sum_q = s_sum;
         qc.qnorm = sqrtf(s_n2);
         qc.k1x = -0.5f * s_sum;
         const float cb = -((float)(1u << ex_bits) - 0.5f);
         qc.kbx = cb * s_sum;
         qc.scale = (float)(1u << ex_bits);
-        qc.pad = 0.0f;
         consts[q] = qc;
     }
 }

@@ -427,6 +427,10 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #endif
     if (scanner) {
         // ------------------------------------------------------------------ scanner waves
+        // Per-tile metadata is pipelined: work item three tiles ahead, factor rows + probe constants two
+        // ahead, sign codes one ahead — and the codes of a block are only fetched if the block survives the
+        // block-level bound below.
+        struct Meta { float f_add, f_rescale, f_error, g_add, g_err, dotqc; };
         auto load_wi = [&](uint32_t t) -> WorkItem {
             const uint32_t s = t * kTileBlocks + hw;
             WorkItem w;
@@ -434,42 +438,79 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             if (s < ns) w = wl[s];
             return w;
         };
-        WorkItem wi_c = load_wi(0), wi_n = load_wi(1);
+        auto load_meta = [&](const WorkItem& w) -> Meta {
+            const float* fac = reinterpret_cast<const float*>(P.blocks + (size_t)w.gblock * stride + (size_t)Dc * 4);
+            const ProbeInfo pi = probe[w.rank_nvalid >> 6];
+            Meta m;
+            m.f_add = fac[l32]; m.f_rescale = fac[32 + l32]; m.f_error = fac[64 + l32];
+            m.g_add = pi.g_add; m.g_err = pi.g_err; m.dotqc = pi.dotqc;
+            return m;
+        };
+        // lower bound of one candidate as a function of its (not yet known) accumulator value: the exact
+        // operation sequence of the epilogue, so floating-point monotonicity carries over
+        auto lb_of = [&](const Meta& m, float accu_f) -> float {
+            const float ip = fmaf(qc.delta, accu_f, qc.sum_vl);
+            const float tt = ip + qc.k1x;
+            const float rs = m.f_rescale * tt;
+            float est = m.f_add + m.g_add;
+            est = est + rs;
+            const float er = m.f_error * m.g_err;
+            return est - er;
+        };
+        // Block-level bound: accu of any code lies in [amin, amax] and lb is monotone in accu (direction =
+        // sign of f_rescale), so min(lb(amin), lb(amax)) <= lb(true accu).  If that already reaches the
+        // (stale, hence larger) threshold for every lane of the wave, the reference skips all of these
+        // candidates too and the block's codes need not be read at all.  Disabled when accu could wrap
+        // (amax > 65535) and when filtered diagnostics need per-candidate filter tests.
+        const bool bound_ok = qc.amax <= 65535.0f && !(P.filter && P.diag);
+        auto wave_live = [&](const WorkItem& w, const Meta& m, float T) -> bool {
+            if (!bound_ok) return true;
+            const float a = lb_of(m, qc.amin), b = lb_of(m, qc.amax);
+            const bool prunable = finite_f(a) && finite_f(b) && fminf(a, b) >= T;
+            const bool ok = (l32 >= (w.rank_nvalid & 63u)) || prunable;
+            return __ballot(ok) != ~0ull;
+        };
+        WorkItem wi_c = load_wi(0), wi_n = load_wi(1), wi_nn = load_wi(2);
+        Meta m_c = load_meta(wi_c), m_n = load_meta(wi_n);
+        bool live_c = true; // T = +inf at tile 0: nothing is prunable
         CodeRegs<DT> cc, cn;
         if (DT) load_codes<DT>(cc, P.blocks + (size_t)wi_c.gblock * stride, l32);
         for (uint32_t t = 0; t < ntiles; ++t) {
             const uint32_t buf = t & 1u;
             const uint8_t* blk = P.blocks + (size_t)wi_c.gblock * stride;
-            // issue everything the next tile needs before touching LDS
-            if (DT) load_codes<DT>(cn, P.blocks + (size_t)wi_n.gblock * stride, l32);
-            const WorkItem wi_nn = load_wi(t + 2);
-            const uint32_t rank = wi_c.rank_nvalid >> 6, nvalid = wi_c.rank_nvalid & 63u;
-            const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
-            const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
-            const ProbeInfo pi = probe[rank];
             const float T = s_T;
-            STAMP(st_a);
-            const uint32_t accu = (DT ? lookup_codes<DT>(cc, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
-#ifdef RBQ_STAMPS
-            asm volatile("" :: "v"(accu));
-            STAMP(st_b); st_look += st_b - st_a;
-#endif
-            // compute_batch_distances_u16 (AVX2 body): only the first op is fused
-            const float ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
-            const float tt = ip + qc.k1x;
-            const float rs = f_rescale * tt;
-            float est = f_add + pi.g_add;
-            est = est + rs;
-            const float er = f_error * pi.g_err;
-            float lb = est - er;
+            // next tile: decide with the current (stale for it) threshold, fetch codes only if needed
+            const bool live_n = wave_live(wi_n, m_n, T);
+            if (DT && live_n) load_codes<DT>(cn, P.blocks + (size_t)wi_n.gblock * stride, l32);
+            const WorkItem wi_nnn = load_wi(t + 3);
+            const Meta m_nn = load_meta(wi_nn);
+            const uint32_t nvalid = wi_c.rank_nvalid & 63u;
             const uint32_t slot = wi_c.gblock * 32u + l32;
             bool valid = l32 < nvalid;
             if (valid && P.filter) {
                 const uint32_t id32 = (uint32_t)P.ids[slot];
                 valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
             }
-            if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(pi.dotqc + qc.qnorm);
-            const bool surv = valid && (lb < T);
+            bool surv = false;
+            float lb = 0.0f, ip = 0.0f, est = 0.0f;
+            if (live_c) { // wave-uniform
+                STAMP(st_a);
+                const uint32_t accu = (DT ? lookup_codes<DT>(cc, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
+#ifdef RBQ_STAMPS
+                asm volatile("" :: "v"(accu));
+                STAMP(st_b); st_look += st_b - st_a;
+#endif
+                // compute_batch_distances_u16 (AVX2 body): only the first op is fused
+                ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
+                const float tt = ip + qc.k1x;
+                const float rs = m_c.f_rescale * tt;
+                est = m_c.f_add + m_c.g_add;
+                est = est + rs;
+                const float er = m_c.f_error * m_c.g_err;
+                lb = est - er;
+                if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(m_c.dotqc + qc.qnorm);
+                surv = valid && (lb < T);
+            }
             if (valid && !surv) ++n_skip;
             const unsigned long long bal = __ballot(surv);
             const uint32_t mask32 = (uint32_t)(bal >> (half * 32));
@@ -479,7 +520,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 q_slot[e] = slot;
                 q_lb[e] = lb;
                 q_ip[e] = ip;
-                q_gadd[e] = pi.g_add;
+                q_gadd[e] = m_c.g_add;
                 q_d[e] = est;
             }
             STAMP(st_a);
@@ -503,8 +544,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 STAMP(st_b); st_heavy += st_b - st_a; ++st_nheavy;
 #endif
             }
-            wi_c = wi_n;
-            wi_n = wi_nn;
+            wi_c = wi_n; wi_n = wi_nn; wi_nn = wi_nnn;
+            m_c = m_n; m_n = m_nn;
+            live_c = live_n;
             if (DT) cc = cn;
         }
         lds_barrier(); // F: replay wave has consumed the last tile
