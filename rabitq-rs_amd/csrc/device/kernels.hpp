@@ -482,7 +482,9 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
         uint32_t cid = (uint32_t)(sel[r] & 0xffffffffu);
         float s = sc[cid], dist, dot;
         const float* c = cent + (size_t)cid * D;
-        if (metric == 0) { dist = s; dot = canon_dot(qrot, c, D); }
+        // L2: score IS the centroid distance; the dot product only feeds the non-finite lower-bound
+        // fallback of the IP metric (src/ivf.rs:2031-2042), so it is not computed here.
+        if (metric == 0) { dist = s; dot = 0.0f; }
         else { dot = s; dist = canon_l2(qrot, c, D); }
         ProbeInfo pi;
         pi.g_add = metric == 0 ? dist : -dot;

@@ -83,7 +83,7 @@ struct rbq_index {
     float fac = 1.0f;
     // device arrays
     void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
-         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr;
+         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr;
     // host
     std::vector<uint32_t> h_list_n;
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
@@ -101,7 +101,7 @@ void free_index(rbq_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (void* p : {ix->d_rot_blob, ix->d_centroids, ix->d_blocks, ix->d_ids, ix->d_ex, ix->d_fadd_ex, ix->d_fres_ex,
-                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total})
+                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum})
         if (p) (void)hipFree(p);
     for (Workspace* w : ix->pool) { w->release(); delete w; }
     for (auto& sp : ix->prof)
@@ -142,13 +142,12 @@ void relayout_ex(const uint8_t* src, uint32_t D, uint32_t ex_bits, uint8_t* dst)
                 codes[l] = low4 | (top2 << 4);
             }
         }
-        const uint32_t bit = t * ex_bits, idx = bit >> 5, sh = bit & 31u;
+        const uint32_t cpu = ex_cpu(ex_bits), unit = t / cpu, k = t % cpu;
+        const uint32_t bit = k * ex_bits, idx = bit >> 5, sh = bit & 31u; // inside the 128-bit unit
         for (uint32_t l = 0; l < 16; ++l) {
-            out[((idx >> 2) * 16 + l) * 4 + (idx & 3u)] |= codes[l] << sh;
-            if (sh + ex_bits > 32) {
-                const uint32_t i2 = idx + 1;
-                out[((i2 >> 2) * 16 + l) * 4 + (i2 & 3u)] |= codes[l] >> (32 - sh);
-            }
+            uint32_t* u = out + (unit * 16 + l) * 4;
+            u[idx] |= codes[l] << sh;
+            if (sh + ex_bits > 32) u[idx + 1] |= codes[l] >> (32 - sh);
         }
     }
 }
@@ -244,12 +243,31 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     std::vector<uint64_t> ids(nblocks * 32, ~0ull);
     std::vector<uint8_t> ex(exd ? nblocks * 32 * exd + 256 : 0);
     std::vector<float> fa(ix->ex_bits ? nblocks * 32 : 0), fr(ix->ex_bits ? nblocks * 32 : 0);
+    std::vector<BlockSummary> bsum(nblocks);
     for (uint64_t c = 0; c < ix->n_lists; ++c) {
         const rbq_list_view& L = lists[c];
         std::memcpy(&cent[c * D], L.centroid, sizeof(float) * D);
         const uint64_t nb = (L.n + 31) / 32;
-        for (uint64_t b = 0; b < nb; ++b)
+        for (uint64_t b = 0; b < nb; ++b) {
             relayout_block(L.batch_data + b * ref_stride, D, Dc, &blocks[(gb0[c] + b) * dev_stride]);
+            // factor ranges over the block's real vectors (block-level lower bound of k_scan)
+            float fac[96];
+            std::memcpy(fac, L.batch_data + b * ref_stride + (size_t)D * 4, 384);
+            const uint32_t nv = (uint32_t)std::min<uint64_t>(32, L.n - b * 32);
+            BlockSummary bs;
+            bs.fadd_min = bs.fres_min = bs.ferr_min = INFINITY;
+            bs.fadd_max = bs.fres_max = bs.ferr_max = -INFINITY;
+            bs.usable = 1; bs.pad = 0;
+            for (uint32_t v = 0; v < nv; ++v) {
+                const float a = fac[v], r = fac[32 + v], e = fac[64 + v];
+                if (!std::isfinite(a) || !std::isfinite(r) || !std::isfinite(e)) bs.usable = 0;
+                bs.fadd_min = std::min(bs.fadd_min, a); bs.fadd_max = std::max(bs.fadd_max, a);
+                bs.fres_min = std::min(bs.fres_min, r); bs.fres_max = std::max(bs.fres_max, r);
+                bs.ferr_min = std::min(bs.ferr_min, e); bs.ferr_max = std::max(bs.ferr_max, e);
+            }
+            if (!bs.usable) { bs.fadd_min = bs.fadd_max = bs.fres_min = bs.fres_max = bs.ferr_min = bs.ferr_max = 0.0f; }
+            bsum[gb0[c] + b] = bs;
+        }
         const size_t s0 = (size_t)gb0[c] * 32;
         if (L.n) {
             std::memcpy(&ids[s0], L.ids, L.n * 8);
@@ -275,6 +293,7 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     UP(d_rot_blob, blob); UP(d_centroids, cent); UP(d_blocks, blocks); UP(d_ids, ids); UP(d_ex, ex);
     UP(d_fadd_ex, fa); UP(d_fres_ex, fr); UP(d_list_gb0, gb0); UP(d_list_n, ln);
     { std::vector<unsigned long long> z(1, 0); UP(d_prof_total, z); }
+    UP(d_bsum, bsum);
 #undef UP
     *out = ix;
     return RBQ_OK;
@@ -385,12 +404,13 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         ScanParams P;
         P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
         P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
+        P.bsum = (const BlockSummary*)ix->d_bsum;
         P.lut = (const uint8_t*)w->lut.p; P.rot = (const float*)w->rot.p; P.consts = (const QueryConsts*)w->consts.p;
         P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const WorkItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
         P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
         P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
         P.D = D; P.Dc = Dc; P.nprobe = nprobe; P.top_k = top_k; P.metric = ix->metric; P.ex_bits = ix->ex_bits;
-        const size_t lds = scan_lds_bytes(Dc, D, top_k);
+        const size_t lds = scan_lds_bytes(Dc, D, ix->ex_bits, top_k);
         hipError_t e;
         if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
         else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream);

@@ -22,12 +22,21 @@
 
 namespace rbq {
 
+// Per-block factor ranges over the block's REAL vectors, computed once at index creation.  Every float op of
+// the epilogue is monotone in each operand, so evaluating it on these extremes brackets every lane's lower
+// bound: lbmin <= lb_v <= lbmax.  `usable` is 0 when any factor is non-finite (the block is then never skipped).
+struct BlockSummary {
+    float fadd_min, fadd_max, fres_min, fres_max, ferr_min, ferr_max;
+    uint32_t usable, pad;
+};
+
 struct ScanParams {
     const uint8_t* blocks;   // [n_blocks][4Dc + 384]: lane-major sign codes | f_add[32] | f_rescale[32] | f_error[32]
     const uint64_t* ids;     // [n_blocks*32]
     const uint8_t* ex_codes; // [n_blocks*32][ex_bytes_dev]: lane-major ex codes, see ex_w4()
     const float* f_add_ex;   // [n_blocks*32]
     const float* f_rescale_ex;
+    const BlockSummary* bsum; // [n_blocks] factor ranges of each block (block-level lower bound)
     const uint8_t* lut;      // [nq][4Dc] (pair-swapped codebook order); Dc = D rounded up to x64
     const float* rot;        // [nq][D]
     const QueryConsts* consts;
@@ -62,12 +71,20 @@ constexpr int kTileBlocks = 2 * kNScan;         // 32-vector blocks per tile (on
 constexpr int kTileCand = kTileBlocks * 32;     // candidates per tile
 constexpr uint32_t kLightMax = RBQ_LIGHT_MAX;   // tiles with more survivors than this run synchronously
 
-// Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 x 16 B, stored [j][lane][16 B];
-// lane l holds the codes of dims 16t+l (t = 0..D/16-1) as a little-endian bit string, ex bits each.
+// Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 units of 16 B, stored [unit][lane][16 B].
+// Lane l holds the codes of dims 16t+l (t = 0..D/16-1); unit j packs codes t = j*CPU .. j*CPU+CPU-1 as a
+// little-endian 128-bit string, ex bits each, with no code straddling two units (CPU = 128/ex: 21 for 6-bit,
+// 64 for 2-bit).  Unused code slots are zero.
+__host__ __device__ inline uint32_t ex_cpu(uint32_t ex_bits) { return ex_bits ? 128u / ex_bits : 1u; }
 __host__ __device__ inline uint32_t ex_w4(uint32_t D, uint32_t ex_bits) { // 16-byte units per lane
-    return ex_bits ? ((D / 16) * ex_bits + 127u) / 128u : 0u;
+    return ex_bits ? (D / 16 + ex_cpu(ex_bits) - 1) / ex_cpu(ex_bits) : 0u;
 }
 __host__ __device__ inline uint32_t ex_bytes_dev(uint32_t D, uint32_t ex_bits) { return ex_w4(D, ex_bits) * 256u; }
+// length of the zero-padded rotated query in LDS: every code slot of every unit has a (zero) partner
+__host__ __device__ inline uint32_t ex_qlen(uint32_t D, uint32_t ex_bits) {
+    const uint32_t n = ex_w4(D, ex_bits) * ex_cpu(ex_bits) * 16u;
+    return n > D ? n : D;
+}
 
 // LUT pointer in the LDS address space, formed from a plain integer offset.  A pointer derived from the
 // `extern __shared__` symbol carries a link-time relocation that hipcc adds with one v_add_u32 PER LOOKUP
@@ -224,54 +241,31 @@ struct LdsHeap {
 };
 
 // ---- ex-code refine: sum_t code[16t+gl] * q[16t+gl] for one 16-lane group, AVX-512 lane order --------------
-// (ip_packed_ex{2,6}_f32, src/simd.rs:1835-1915: one fused multiply-add per 16-dim step per lane, then the
-// _mm512_reduce_add_ps halving tree.)  The vector's lane-major ex record is loaded with W4 16-byte loads per
-// lane and decoded from registers.
-template <int DT, int EX>
-struct ExRegs {
-    static constexpr int W4 = ((DT / 16) * EX + 127) / 128;
-    uint32_t w[W4 * 4 + 1];
-};
-template <int DT, int EX>
-__device__ __forceinline__ void ex_load(ExRegs<DT, EX>& r, const uint8_t* __restrict__ ex, uint32_t gl) {
+// (ip_packed_ex{2,6}_f32, src/simd.rs:1835-1915: one fused multiply-add per 16-dim step per lane, t ascending,
+// then the _mm512_reduce_add_ps halving tree.)  Units are walked in a runtime loop (next unit prefetched),
+// the CPU codes of a unit are decoded from 4 registers with compile-time shifts.  `sq` is the zero-padded
+// rotated query (ex_qlen floats): padded code slots are 0 and 0*q + s == s exactly.
+template <int EX>
+__device__ __forceinline__ float ex_dot_units(const uint8_t* __restrict__ ex, const float* sq, uint32_t gl, uint32_t nunits) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
     const uint4* p = reinterpret_cast<const uint4*>(ex) + gl;
-#pragma unroll
-    for (int j = 0; j < ExRegs<DT, EX>::W4; ++j) {
-        const uint4 v = p[j * 16];
-        r.w[4 * j] = v.x; r.w[4 * j + 1] = v.y; r.w[4 * j + 2] = v.z; r.w[4 * j + 3] = v.w;
-    }
-    r.w[ExRegs<DT, EX>::W4 * 4] = 0;
-}
-template <int DT, int EX>
-__device__ __forceinline__ float ex_dot(const ExRegs<DT, EX>& r, const float* s_q, uint32_t gl) {
     float sacc = 0.0f;
+    uint4 cur = p[0];
+#pragma unroll 1
+    for (uint32_t j = 0; j < nunits; ++j) {
+        const uint4 nxt = p[(j + 1 < nunits ? j + 1 : j) * 16];
+        const uint32_t w[5] = {cur.x, cur.y, cur.z, cur.w, 0u};
+        const float* qj = sq + (size_t)j * CPU * 16 + gl;
 #pragma unroll
-    for (int t = 0; t < DT / 16; ++t) {
-        constexpr uint32_t mask = (1u << EX) - 1u;
-        const int bit = t * EX, idx = bit >> 5, sh = bit & 31;
-        uint32_t code;
-        if (sh + EX <= 32) code = (r.w[idx] >> sh) & mask;
-        else code = ((r.w[idx] >> sh) | (r.w[idx + 1] << (32 - sh))) & mask;
-        sacc = fmaf((float)code, s_q[16 * t + gl], sacc);
-    }
-    return sacc;
-}
-// runtime-shape fallback (any D, ex in {2,6})
-__device__ inline float ex_dot_lane_rt(const uint8_t* __restrict__ ex, const float* s_q, uint32_t gl, uint32_t D,
-                                       uint32_t ex_bits) {
-    const uint32_t* base = reinterpret_cast<const uint32_t*>(ex);
-    const uint32_t mask = (1u << ex_bits) - 1u;
-    float sacc = 0.0f;
-    for (uint32_t t = 0; t < D / 16; ++t) {
-        const uint32_t bit = t * ex_bits, idx = bit >> 5, sh = bit & 31u;
-        // dword idx of lane gl lives at unit j = idx/4: [j][lane][4 dwords]
-        uint32_t lo = base[((idx >> 2) * 16 + gl) * 4 + (idx & 3u)];
-        uint32_t code = lo >> sh;
-        if (sh + ex_bits > 32) {
-            const uint32_t i2 = idx + 1;
-            code |= base[((i2 >> 2) * 16 + gl) * 4 + (i2 & 3u)] << (32 - sh);
+        for (int k = 0; k < CPU; ++k) {
+            const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+            uint32_t code;
+            if (sh + EX <= 32) code = (w[idx] >> sh) & mask;
+            else code = ((w[idx] >> sh) | (w[idx + 1] << (32 - sh))) & mask;
+            sacc = fmaf((float)code, qj[16 * k], sacc);
         }
-        sacc = fmaf((float)(code & mask), s_q[16 * t + gl], sacc);
+        cur = nxt;
     }
     return sacc;
 }
@@ -335,10 +329,14 @@ struct RegHeap {
 
 // LDS carve-up (dynamic only, LUT at byte 0):
 //   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
-//   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | T, len, nskip, pad
-__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t top_k) {
-    return (size_t)Dc * 4 + (size_t)D * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + 16;
+//   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
+//   T, len, nskip, pad
+constexpr int kWindow = kNScan * 64;               // blocks examined per fill step: one per scanner lane
+constexpr int kQueueCap = 256;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
+static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
+    return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
+           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * 8 + 16;
 }
 
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
     uint8_t* s_lut = smraw;
     float* s_q = reinterpret_cast<float*>(smraw + (size_t)Dc * 4);
-    float* heap_d = s_q + D;
+    float* heap_d = s_q + ex_qlen(D, DT ? (uint32_t)EX : P.ex_bits);
     uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
     uint32_t* q_slot = heap_s + (P.top_k + 1);                      // [2][kTileCand]
     float* q_lb = reinterpret_cast<float*>(q_slot + 2 * kTileCand);
@@ -358,10 +356,13 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     float* q_d = q_gadd + 2 * kTileCand;
     uint32_t* s_list = reinterpret_cast<uint32_t*>(q_d + 2 * kTileCand); // [kTileCand] survivor positions, stream order
     uint32_t* s_mask = s_list + kTileCand;                                // [2][kTileBlocks]
+    WorkItem* s_queue = reinterpret_cast<WorkItem*>(s_mask + 2 * kTileBlocks); // [kQueueCap] live blocks, stream order
+    unsigned long long* s_fmask = reinterpret_cast<unsigned long long*>(s_queue + kQueueCap); // [kNScan] fill-step live masks
     // no static __shared__ in this kernel: the dynamic region must start at LDS address 0 (see lds_lut_ptr)
-    float& s_T = *reinterpret_cast<float*>(s_mask + 2 * kTileBlocks);
-    uint32_t& s_len = *(s_mask + 2 * kTileBlocks + 1);
-    uint32_t* s_nskip = s_mask + 2 * kTileBlocks + 2;
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_fmask + kNScan);
+    float& s_T = *reinterpret_cast<float*>(s_misc);
+    uint32_t& s_len = *(s_misc + 1);
+    uint32_t* s_nskip = s_misc + 2;
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u, half = lane >> 5, l32 = lane & 31u;
@@ -373,22 +374,23 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     const uint32_t ex_bits = DT ? (uint32_t)EX : P.ex_bits;
     const size_t stride = (size_t)Dc * 4 + 384;
     const size_t exb = ex_bytes_dev(D, ex_bits);
+    const uint32_t nunits = ex_w4(D, ex_bits), qlen = ex_qlen(D, ex_bits);
 
     {
         const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
         uint4* dst = reinterpret_cast<uint4*>(s_lut);
         for (uint32_t i = tid; i < Dc / 4; i += kScanThreads) dst[i] = src[i];
-        for (uint32_t i = tid; i < D; i += kScanThreads) s_q[i] = P.rot[(size_t)q * D + i];
+        for (uint32_t i = tid; i < qlen; i += kScanThreads) s_q[i] = i < D ? P.rot[(size_t)q * D + i] : 0.0f;
         if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; }
     }
     const QueryConsts qc = P.consts[q];
     const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
     const WorkItem* wl = P.wl + (size_t)q * P.wl_stride;
     const uint32_t ns = P.nstream[q];
-    const uint32_t ntiles = (ns + kTileBlocks - 1) / kTileBlocks;
     __syncthreads();
 
     uint32_t n_skip = 0, n_ext = 0, n_est = 0; // n_skip: every thread; n_ext/n_est: replay wave (uniform)
+    const bool count_skips = P.diag != nullptr;
 
     // refine survivors i = g0, g0+gstep, ... of tile buffer `buf`; 16 lanes per survivor
     auto refine = [&](uint32_t buf, uint32_t S, uint32_t g0, uint32_t gstep) {
@@ -397,14 +399,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             const uint32_t e = buf * kTileCand + s_list[i];
             const uint32_t sl = q_slot[e];
             const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
-            float sacc;
-            if (DT) {
-                ExRegs<DT ? DT : 16, (DT && EX) ? EX : 2> r;
-                ex_load(r, ex, gl);
-                sacc = ex_dot(r, s_q, gl);
-            } else {
-                sacc = ex_dot_lane_rt(ex, s_q, gl, D, ex_bits);
-            }
+            float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, s_q, gl, nunits) : ex_dot_units<2>(ex, s_q, gl, nunits);
             sacc = group16_reduce(sacc);
             if (gl == 0) {
                 float tt2 = qc.scale * q_ip[e];
@@ -417,73 +412,133 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         }
     };
 
+    struct Meta { float f_add, f_rescale, f_error, g_add, g_err, dotqc; };
+    auto load_meta = [&](const WorkItem& w) -> Meta {
+        const float* fac = reinterpret_cast<const float*>(P.blocks + (size_t)w.gblock * stride + (size_t)Dc * 4);
+        const ProbeInfo pi = probe[w.rank_nvalid >> 6];
+        Meta m;
+        m.f_add = fac[l32]; m.f_rescale = fac[32 + l32]; m.f_error = fac[64 + l32];
+        m.g_add = pi.g_add; m.g_err = pi.g_err; m.dotqc = pi.dotqc;
+        return m;
+    };
+    // lower bound of one candidate as a function of its accumulator value: the exact operation sequence of
+    // the epilogue (compute_batch_distances_u16, AVX2 body: only the first op is fused), so floating-point
+    // monotonicity carries over to the bound below
+    auto lb_of = [&](const Meta& m, float accu_f, float& ip, float& est) -> float {
+        ip = fmaf(qc.delta, accu_f, qc.sum_vl);
+        const float tt = ip + qc.k1x;
+        const float rs = m.f_rescale * tt;
+        est = m.f_add + m.g_add;
+        est = est + rs;
+        const float er = m.f_error * m.g_err;
+        return est - er;
+    };
+    // Block-level bound: accu of any code lies in [amin, amax] and lb is monotone in accu (direction = sign
+    // of f_rescale), so min(lb(amin), lb(amax)) <= lb(true accu).  If that already reaches the (stale, hence
+    // larger) threshold for every lane, the reference skips all of these candidates too and the block's
+    // codes are never read.  Disabled when accu could wrap (amax > 65535) and when filtered diagnostics need
+    // per-candidate filter tests.
+    const bool bound_ok = qc.amax <= 65535.0f && !(P.filter && P.diag);
+    auto lane_prunable = [&](const WorkItem& w, const Meta& m, float T) -> bool {
+        float d0, d1;
+        const float a = lb_of(m, qc.amin, d0, d1), b = lb_of(m, qc.amax, d0, d1);
+        const bool prunable = finite_f(a) && finite_f(b) && fminf(a, b) >= T;
+        return (l32 >= (w.rank_nvalid & 63u)) || prunable;
+    };
+
+    // Uniform loop state (identical in every wave; advanced only from LDS values published before a barrier)
+    uint32_t pos = 0;                 // next unexamined stream block
+    uint32_t qhead = 0, qcount = 0;   // live-block FIFO
+    uint32_t tile = 0;                // tiles published so far (buffer = tile & 1)
+    // replay-wave state
+    const bool reg_heap = top_k < 64;
+    RegHeap rh{0, 0u, 0u};
+    LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
-    unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0;
-    uint32_t st_nheavy = 0, st_surv = 0;
+    unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
+    uint32_t st_nheavy = 0, st_surv = 0, st_ntile = 0, st_dead = 0;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
-    unsigned long long st_a, st_b;
 #else
 #define STAMP(x)
 #endif
-    if (scanner) {
-        // ------------------------------------------------------------------ scanner waves
-        // Per-tile metadata is pipelined: work item three tiles ahead, factor rows + probe constants two
-        // ahead, sign codes one ahead — and the codes of a block are only fetched if the block survives the
-        // block-level bound below.
-        struct Meta { float f_add, f_rescale, f_error, g_add, g_err, dotqc; };
-        auto load_wi = [&](uint32_t t) -> WorkItem {
-            const uint32_t s = t * kTileBlocks + hw;
-            WorkItem w;
-            w.gblock = 0; w.rank_nvalid = 0; // nvalid 0 -> every lane invalid; block 0 keeps the loads in range
-            if (s < ns) w = wl[s];
-            return w;
-        };
-        auto load_meta = [&](const WorkItem& w) -> Meta {
-            const float* fac = reinterpret_cast<const float*>(P.blocks + (size_t)w.gblock * stride + (size_t)Dc * 4);
-            const ProbeInfo pi = probe[w.rank_nvalid >> 6];
-            Meta m;
-            m.f_add = fac[l32]; m.f_rescale = fac[32 + l32]; m.f_error = fac[64 + l32];
-            m.g_add = pi.g_add; m.g_err = pi.g_err; m.dotqc = pi.dotqc;
-            return m;
-        };
-        // lower bound of one candidate as a function of its (not yet known) accumulator value: the exact
-        // operation sequence of the epilogue, so floating-point monotonicity carries over
-        auto lb_of = [&](const Meta& m, float accu_f) -> float {
-            const float ip = fmaf(qc.delta, accu_f, qc.sum_vl);
-            const float tt = ip + qc.k1x;
-            const float rs = m.f_rescale * tt;
-            float est = m.f_add + m.g_add;
-            est = est + rs;
-            const float er = m.f_error * m.g_err;
-            return est - er;
-        };
-        // Block-level bound: accu of any code lies in [amin, amax] and lb is monotone in accu (direction =
-        // sign of f_rescale), so min(lb(amin), lb(amax)) <= lb(true accu).  If that already reaches the
-        // (stale, hence larger) threshold for every lane of the wave, the reference skips all of these
-        // candidates too and the block's codes need not be read at all.  Disabled when accu could wrap
-        // (amax > 65535) and when filtered diagnostics need per-candidate filter tests.
-        const bool bound_ok = qc.amax <= 65535.0f && !(P.filter && P.diag);
-        auto wave_live = [&](const WorkItem& w, const Meta& m, float T) -> bool {
-            if (!bound_ok) return true;
-            const float a = lb_of(m, qc.amin), b = lb_of(m, qc.amax);
-            const bool prunable = finite_f(a) && finite_f(b) && fminf(a, b) >= T;
-            const bool ok = (l32 >= (w.rank_nvalid & 63u)) || prunable;
-            return __ballot(ok) != ~0ull;
-        };
-        WorkItem wi_c = load_wi(0), wi_n = load_wi(1), wi_nn = load_wi(2);
-        Meta m_c = load_meta(wi_c), m_n = load_meta(wi_n);
-        bool live_c = true; // T = +inf at tile 0: nothing is prunable
-        CodeRegs<DT> cc, cn;
-        if (DT) load_codes<DT>(cc, P.blocks + (size_t)wi_c.gblock * stride, l32);
-        for (uint32_t t = 0; t < ntiles; ++t) {
-            const uint32_t buf = t & 1u;
+
+    while (true) {
+        if (pos < ns && qcount < (uint32_t)kTileBlocks) {
+            // ---------------------------------------------------------------- fill step: examine kWindow blocks
+            STAMP(st_c);
+            if (scanner) {
+                // one lane per block: work item -> block summary + probe constants -> block-level bound
+                const float T = s_T;
+                const uint32_t idx = pos + wave * 64u + lane;
+                WorkItem w;
+                w.gblock = 0; w.rank_nvalid = 0;
+                bool live = false;
+                if (idx < ns) {
+                    w = wl[idx];
+                    live = true;
+                    if (bound_ok) {
+                        const BlockSummary bs = P.bsum[w.gblock];
+                        const ProbeInfo pi = probe[w.rank_nvalid >> 6];
+                        const float tA = fmaf(qc.delta, qc.amin, qc.sum_vl) + qc.k1x;
+                        const float tB = fmaf(qc.delta, qc.amax, qc.sum_vl) + qc.k1x;
+                        const float r0 = bs.fres_min * tA, r1 = bs.fres_min * tB, r2 = bs.fres_max * tA, r3 = bs.fres_max * tB;
+                        const float rmin = fminf(fminf(r0, r1), fminf(r2, r3)), rmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+                        float elo = bs.fadd_min + pi.g_add;
+                        elo = elo + rmin;
+                        const float lbmin = elo - bs.ferr_max * pi.g_err;
+                        float ehi = bs.fadd_max + pi.g_add;
+                        ehi = ehi + rmax;
+                        const float lbmax = ehi - bs.ferr_min * pi.g_err;
+                        const bool fin = finite_f(r0) && finite_f(r1) && finite_f(r2) && finite_f(r3) && finite_f(lbmin) &&
+                                         finite_f(lbmax) && finite_f(elo) && finite_f(ehi);
+                        if (bs.usable && fin && lbmin >= T) {
+                            live = false;
+                            if (count_skips) n_skip += w.rank_nvalid & 63u;
+                        }
+                    }
+                }
+                const unsigned long long livemask = __ballot(live);
+                if (lane == 0) s_fmask[wave] = livemask;
+                lds_barrier(); // X1: live masks published
+                uint32_t off = 0, total = 0;
+#pragma unroll
+                for (int j = 0; j < kNScan; ++j) {
+                    const uint32_t c = __popcll(s_fmask[j]);
+                    off += (uint32_t)j < wave ? c : 0u;
+                    total += c;
+                }
+                if (live) s_queue[(qhead + qcount + off + __popcll(livemask & ((1ull << lane) - 1ull))) % kQueueCap] = w;
+                lds_barrier(); // X2: queue entries visible
+                qcount += total;
+            } else {
+                lds_barrier(); // X1
+                uint32_t total = 0;
+#pragma unroll
+                for (int j = 0; j < kNScan; ++j) total += __popcll(s_fmask[j]);
+                lds_barrier(); // X2
+                qcount += total;
+            }
+            pos += kWindow;
+#ifdef RBQ_STAMPS
+            STAMP(st_b); st_fill += st_b - st_c;
+#endif
+            continue;
+        }
+        if (qcount == 0) break;
+        // -------------------------------------------------------------------- tile step
+        const uint32_t n = qcount < (uint32_t)kTileBlocks ? qcount : (uint32_t)kTileBlocks;
+        const uint32_t buf = tile & 1u;
+        if (scanner) {
+            WorkItem wi_c;
+            wi_c.gblock = 0; wi_c.rank_nvalid = 0;
+            if (hw < n) wi_c = s_queue[(qhead + hw) % kQueueCap];
             const uint8_t* blk = P.blocks + (size_t)wi_c.gblock * stride;
+            const Meta m_c = load_meta(wi_c);
             const float T = s_T;
-            // next tile: decide with the current (stale for it) threshold, fetch codes only if needed
-            const bool live_n = wave_live(wi_n, m_n, T);
-            if (DT && live_n) load_codes<DT>(cn, P.blocks + (size_t)wi_n.gblock * stride, l32);
-            const WorkItem wi_nnn = load_wi(t + 3);
-            const Meta m_nn = load_meta(wi_nn);
+            // per-lane bound with the fresh threshold: the whole wave may be prunable without reading codes
+            const bool live_c = !bound_ok || (__ballot(lane_prunable(wi_c, m_c, T)) != ~0ull);
+            CodeRegs<DT> cc;
+            if (DT && live_c) load_codes<DT>(cc, blk, l32);
             const uint32_t nvalid = wi_c.rank_nvalid & 63u;
             const uint32_t slot = wi_c.gblock * 32u + l32;
             bool valid = l32 < nvalid;
@@ -493,6 +548,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             }
             bool surv = false;
             float lb = 0.0f, ip = 0.0f, est = 0.0f;
+#ifdef RBQ_STAMPS
+            ++st_ntile; if (!live_c) ++st_dead;
+#endif
             if (live_c) { // wave-uniform
                 STAMP(st_a);
                 const uint32_t accu = (DT ? lookup_codes<DT>(cc, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
@@ -500,14 +558,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 asm volatile("" :: "v"(accu));
                 STAMP(st_b); st_look += st_b - st_a;
 #endif
-                // compute_batch_distances_u16 (AVX2 body): only the first op is fused
-                ip = fmaf(qc.delta, (float)accu, qc.sum_vl);
-                const float tt = ip + qc.k1x;
-                const float rs = m_c.f_rescale * tt;
-                est = m_c.f_add + m_c.g_add;
-                est = est + rs;
-                const float er = m_c.f_error * m_c.g_err;
-                lb = est - er;
+                lb = lb_of(m_c, (float)accu, ip, est);
                 if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(m_c.dotqc + qc.qnorm);
                 surv = valid && (lb < T);
             }
@@ -524,7 +575,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 q_d[e] = est;
             }
             STAMP(st_a);
-            lds_barrier(); // A: tile t is published to the replay wave
+            lds_barrier(); // A: this tile is published to the replay wave
 #ifdef RBQ_STAMPS
             STAMP(st_b); st_waitA += st_b - st_a;
 #endif
@@ -544,19 +595,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 STAMP(st_b); st_heavy += st_b - st_a; ++st_nheavy;
 #endif
             }
-            wi_c = wi_n; wi_n = wi_nn; wi_nn = wi_nnn;
-            m_c = m_n; m_n = m_nn;
-            live_c = live_n;
-            if (DT) cc = cn;
-        }
-        lds_barrier(); // F: replay wave has consumed the last tile
-    } else {
-        // ------------------------------------------------------------------ replay wave (uniform control flow)
-        const bool reg_heap = top_k < 64;
-        RegHeap rh{0, 0u, 0u};
-        LdsHeap lh{heap_d, heap_s, 0};
-        for (uint32_t t = 0; t < ntiles; ++t) {
-            const uint32_t buf = t & 1u;
+        } else {
+            // ---------------------------------------------------------------- replay wave (uniform control flow)
             lds_barrier(); // A
             // compaction in stream order: block by block, lane order within the block
             for (uint32_t b = half; b < (uint32_t)kTileBlocks; b += 2) {
@@ -621,6 +661,12 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             }
             if (heavy) lds_barrier(); // D
         }
+        qhead = (qhead + n) % kQueueCap;
+        qcount -= n;
+        ++tile;
+    }
+    lds_barrier(); // F: the replay wave has consumed the last tile
+    if (!scanner) {
         if (reg_heap) { // spill the register heap to LDS for the final heap-sort
             if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
             lh.len = rh.len;
@@ -630,7 +676,6 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             lh.into_sorted();
             s_len = lh.len;
         }
-        lds_barrier(); // F
         if (lane != 0) { n_skip = 0; n_ext = 0; n_est = 0; } // uniform counters: report them once
     }
 
@@ -650,9 +695,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
     if (tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
         st_total = __builtin_amdgcn_s_memtime() - st_total;
-        P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | (st_waitA << 32);
+        P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | ((unsigned long long)(st_ntile | (st_dead << 16)) << 32);
         P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | ((unsigned long long)st_nheavy << 32);
-        P.diag[(size_t)q * 3 + 2] = (unsigned long long)st_surv | (st_look << 32);
+        P.diag[(size_t)q * 3 + 2] = (unsigned long long)st_surv | (st_fill << 32);
     }
     if (wave == (uint32_t)kNScan && lane == 0) { P.out_counts[q] = len; }
     if (false) {

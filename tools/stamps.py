@@ -15,9 +15,10 @@ q = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).cpu().nu
 for _ in range(2):
     ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
 d = diag.astype(np.uint64)
-heavy = (d[:, 0] & 0xffffffff).astype(np.float64); waitA = (d[:, 0] >> 32).astype(np.float64)
+heavy = (d[:, 0] & 0xffffffff).astype(np.float64); waitA = np.zeros(len(d)); ntile = ((d[:, 0] >> 32) & 0xffff).astype(np.float64); dead = (d[:, 0] >> 48).astype(np.float64)
 total = (d[:, 1] & 0xffffffff).astype(np.float64); nheavy = (d[:, 1] >> 32).astype(np.float64)
 surv = (d[:, 2] & 0xffffffff).astype(np.float64); look = (d[:, 2] >> 32).astype(np.float64)
-print("per-query means (cycles of s_memtime): total %.0f  lookups %.0f (%.0f%%)  waitA %.0f (%.0f%%)  heavy %.0f (%.0f%%)" % (
+print("per-query means (cycles of s_memtime): total %.0f  fill %.0f (%.0f%%)  waitA %.0f (%.0f%%)  heavy %.0f (%.0f%%)" % (
     total.mean(), look.mean(), 100 * look.mean() / total.mean(), waitA.mean(), 100 * waitA.mean() / total.mean(), heavy.mean(), 100 * heavy.mean() / total.mean()))
+print("tiles/query %.1f dead(wave0) %.1f" % (ntile.mean(), dead.mean()))
 print("heavy tiles/query %.1f  survivors/query %.0f  total p50 %.0f p99 %.0f max %.0f" % (nheavy.mean(), surv.mean(), np.percentile(total, 50), np.percentile(total, 99), total.max()))
