@@ -269,6 +269,36 @@ __device__ __forceinline__ float ex_dot_units(const uint8_t* __restrict__ ex, co
     }
     return sacc;
 }
+// Same arithmetic with all units of a vector resident in registers (nunits <= kExRegUnits), so that the units
+// of the NEXT survivor can be in flight while this one is evaluated (heavy tiles: hundreds of survivors).
+constexpr int kExRegUnits = 4;
+__device__ __forceinline__ void ex_load_all(uint4 (&u)[kExRegUnits], const uint8_t* __restrict__ ex, uint32_t gl, uint32_t nunits) {
+    const uint4* p = reinterpret_cast<const uint4*>(ex) + gl;
+#pragma unroll
+    for (int j = 0; j < kExRegUnits; ++j) u[j] = p[((uint32_t)j < nunits ? j : 0) * 16];
+}
+template <int EX>
+__device__ __forceinline__ float ex_dot_all(const uint4 (&u)[kExRegUnits], const float* sq, uint32_t gl, uint32_t nunits) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    float sacc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kExRegUnits; ++j) {
+        if ((uint32_t)j < nunits) { // wave-uniform
+            const uint32_t w[5] = {u[j].x, u[j].y, u[j].z, u[j].w, 0u};
+            const float* qj = sq + j * CPU * 16 + gl;
+#pragma unroll
+            for (int k = 0; k < CPU; ++k) {
+                const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+                uint32_t code;
+                if (sh + EX <= 32) code = (w[idx] >> sh) & mask;
+                else code = ((w[idx] >> sh) | (w[idx + 1] << (32 - sh))) & mask;
+                sacc = fmaf((float)code, qj[16 * k], sacc);
+            }
+        }
+    }
+    return sacc;
+}
 __device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_add_ps halving tree
     sacc = sacc + __shfl_xor(sacc, 8, 16);
     sacc = sacc + __shfl_xor(sacc, 4, 16);
@@ -284,18 +314,22 @@ struct RegHeap {
     int hd;      // distance bits of entry `lane`
     uint32_t hs; // slot of entry `lane`
     uint32_t len;
-    __device__ __forceinline__ int d_at(uint32_t i) const { return __builtin_amdgcn_readlane(hd, (int)i); }
-    __device__ __forceinline__ uint32_t s_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)hs, (int)i); }
+    // every index below is wave-uniform; readfirstlane makes that explicit so that hipcc emits a plain
+    // v_readlane instead of a waterfall loop
+    static __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+    __device__ __forceinline__ int d_at(uint32_t i) const { return __builtin_amdgcn_readlane(hd, (int)uni(i)); }
+    __device__ __forceinline__ uint32_t s_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)hs, (int)uni(i)); }
     __device__ __forceinline__ void set(uint32_t i, int d, uint32_t s) { // v_writelane as compare+select
-        const bool me = (__lane_id() == i);
+        const bool me = (__lane_id() == uni(i));
         hd = me ? d : hd;
         hs = me ? s : hs;
     }
     static __device__ __forceinline__ int key(int bits) { return bits ^ (int)(((uint32_t)(bits >> 31)) >> 1); }
     __device__ __forceinline__ void sift_up(uint32_t pos, int ed, uint32_t es) {
         const int ke = key(ed);
+        pos = uni(pos);
         while (pos > 0) {
-            const uint32_t parent = (pos - 1) >> 1;
+            const uint32_t parent = uni((pos - 1) >> 1);
             const int pd = d_at(parent);
             if (ke <= key(pd)) break;
             set(pos, pd, s_at(parent));
@@ -303,9 +337,13 @@ struct RegHeap {
         }
         set(pos, ed, es);
     }
-    __device__ __forceinline__ void push(int dbits, uint32_t slot) { sift_up(len++, dbits, slot); }
+    __device__ __forceinline__ void push(int dbits, uint32_t slot) {
+        const uint32_t p = uni(len);
+        len = p + 1;
+        sift_up(p, dbits, slot);
+    }
     __device__ __forceinline__ void pop() {
-        --len;
+        len = uni(len - 1);
         if (len == 0) return;
         const int ed = d_at(len);
         const uint32_t es = s_at(len);
@@ -314,10 +352,10 @@ struct RegHeap {
         while (end >= 2 && child <= end - 2) {
             const int c0 = d_at(child), c1 = d_at(child + 1);
             const bool right = key(c0) <= key(c1);
-            child += right ? 1u : 0u;
+            child = uni(child + (right ? 1u : 0u));
             set(p, right ? c1 : c0, s_at(child));
             p = child;
-            child = 2 * p + 1;
+            child = uni(2 * p + 1);
         }
         if (child == end - 1) {
             set(p, d_at(child), s_at(child));
@@ -393,21 +431,52 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     const bool count_skips = P.diag != nullptr;
 
     // refine survivors i = g0, g0+gstep, ... of tile buffer `buf`; 16 lanes per survivor
+    auto refine_finish = [&](uint32_t e, uint32_t sl, float sacc) {
+        sacc = group16_reduce(sacc);
+        if ((tid & 15u) == 0) {
+            float tt2 = qc.scale * q_ip[e];
+            tt2 = tt2 + sacc;
+            tt2 = tt2 + qc.kbx;
+            const float a = P.f_add_ex[sl] + q_gadd[e];
+            const float m = P.f_rescale_ex[sl] * tt2;
+            q_d[e] = a + m;
+        }
+    };
     auto refine = [&](uint32_t buf, uint32_t S, uint32_t g0, uint32_t gstep) {
         const uint32_t gl = tid & 15u;
-        for (uint32_t i = g0; i < S; i += gstep) {
-            const uint32_t e = buf * kTileCand + s_list[i];
-            const uint32_t sl = q_slot[e];
-            const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
-            float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, s_q, gl, nunits) : ex_dot_units<2>(ex, s_q, gl, nunits);
-            sacc = group16_reduce(sacc);
-            if (gl == 0) {
-                float tt2 = qc.scale * q_ip[e];
-                tt2 = tt2 + sacc;
-                tt2 = tt2 + qc.kbx;
-                const float a = P.f_add_ex[sl] + q_gadd[e];
-                const float m = P.f_rescale_ex[sl] * tt2;
-                q_d[e] = a + m;
+        if (nunits <= (uint32_t)kExRegUnits) {
+            // software-pipelined over survivors: the next survivor's units are loading while this one is summed
+            uint4 cur[kExRegUnits], nxt[kExRegUnits];
+            uint32_t i = g0, e = 0, sl = 0;
+            if (i < S) {
+                e = buf * kTileCand + s_list[i];
+                sl = q_slot[e];
+                ex_load_all(cur, P.ex_codes + (size_t)sl * exb, gl, nunits);
+            }
+            while (i < S) {
+                const uint32_t ni = i + gstep;
+                uint32_t ne = 0, nsl = 0;
+                if (ni < S) {
+                    ne = buf * kTileCand + s_list[ni];
+                    nsl = q_slot[ne];
+                    ex_load_all(nxt, P.ex_codes + (size_t)nsl * exb, gl, nunits);
+                }
+                uint32_t opaque = 0; // keeps the (survivor-invariant) query reads inside the loop: hoisting
+                asm volatile("" : "+v"(opaque)); // them would cost D/16 registers for the whole kernel
+                const float* sq = s_q + opaque;
+                const float sacc = ex_bits == 6 ? ex_dot_all<6>(cur, sq, gl, nunits) : ex_dot_all<2>(cur, sq, gl, nunits);
+                refine_finish(e, sl, sacc);
+#pragma unroll
+                for (int j = 0; j < kExRegUnits; ++j) cur[j] = nxt[j];
+                i = ni; e = ne; sl = nsl;
+            }
+        } else {
+            for (uint32_t i = g0; i < S; i += gstep) {
+                const uint32_t e = buf * kTileCand + s_list[i];
+                const uint32_t sl = q_slot[e];
+                const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
+                const float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, s_q, gl, nunits) : ex_dot_units<2>(ex, s_q, gl, nunits);
+                refine_finish(e, sl, sacc);
             }
         }
     };
@@ -457,6 +526,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
     uint32_t st_nheavy = 0, st_surv = 0, st_ntile = 0, st_dead = 0;
+    unsigned long long st_hB = 0, st_hR = 0, st_hD = 0;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(x)
@@ -588,11 +658,17 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             if (S > kLightMax) { // synchronous tile: help refining, then wait for the fresh threshold
                 STAMP(st_a);
                 lds_barrier();   // B: survivor list compacted
+#ifdef RBQ_STAMPS
+                STAMP(st_b); st_hB += st_b - st_a;
+#endif
                 if (ex_bits) refine(buf, S, tid >> 4, kScanThreads / 16);
+#ifdef RBQ_STAMPS
+                STAMP(st_c); st_hR += st_c - st_b;
+#endif
                 lds_barrier();   // C: refined distances visible
                 lds_barrier();   // D: replay done, s_T updated
 #ifdef RBQ_STAMPS
-                STAMP(st_b); st_heavy += st_b - st_a; ++st_nheavy;
+                STAMP(st_b); st_hD += st_b - st_c; st_heavy += st_b - st_a; ++st_nheavy;
 #endif
             }
         } else {
@@ -695,7 +771,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
     if (tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
         st_total = __builtin_amdgcn_s_memtime() - st_total;
-        P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | ((unsigned long long)(st_ntile | (st_dead << 16)) << 32);
+        P.diag[(size_t)q * 3 + 0] = (st_hB & 0xfffffull) | ((st_hR & 0xfffffull) << 20) | ((st_hD & 0xffffffull) << 40);
         P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | ((unsigned long long)st_nheavy << 32);
         P.diag[(size_t)q * 3 + 2] = (unsigned long long)st_surv | (st_fill << 32);
     }
