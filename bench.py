@@ -215,6 +215,7 @@ def main():
         "recall_at_10": recall,
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "index_build_s": round(t_build, 1),
+        "rank_fallbacks": int(idx.rank_fallbacks()),
         "roofline": {"bound": "hbm", "kernel": "k_scan", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": scan_ms,

@@ -144,6 +144,9 @@ double rbq_profile_stage_ms(const rbq_index* idx, const char* stage, uint64_t* l
 /* Algorithmic bytes (sum over probed lists of n_c*(D/8+12)) of the
  * scan launches between rbq_profile_begin/end. */
 uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
+/* Number of queries (since creation) whose probe selection fell back from the MFMA shortlist to the
+ * all-lists canonical ranking (shortlist overflow / non-finite scores). Diagnostic. */
+uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
 
 const char* rbq_strerror(int code);
 /* Copies the calling thread's last error detail (e.g. "checksum mismatch",

@@ -23,6 +23,7 @@ constexpr int kThreads = 256;
 
 struct QueryConsts {
     float delta, sum_vl, k1x, kbx, scale, qnorm;
+    float qnorm2, pad0, pad1, pad2; // |q|^2 of the rotated query (approximate ranking, rank_mfma.hpp)
     float amin, amax; // sum over codebooks of the smallest / largest u8 entry: accu of ANY code lies in [amin, amax]
 };
 struct ProbeInfo {
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         qc.delta = delta;
         qc.sum_vl = vl * (float)(D / 4);
         qc.qnorm = sqrtf(s_n2);
+        qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
         qc.k1x = -0.5f * s_sum;
         const float cb = -((float)(1u << ex_bits) - 0.5f);
         qc.kbx = cb * s_sum;

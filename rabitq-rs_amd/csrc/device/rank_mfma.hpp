@@ -1,0 +1,367 @@
+// rank_mfma.hpp — probe selection through an MFMA shortlist (gfx950).
+//
+// Reference: search_fastscan's centroid ranking (src/ivf.rs:1782-1835) with math::l2_distance_sqr / dot in
+// their AVX2 lane order (src/math.rs:154-245).  Ranking all nq x nlist pairs in that exact order costs
+// 3*nq*nlist*D unfused VALU ops; instead
+//   k_rank_mfma    one f32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact f32 FMA chain) gives APPROXIMATE scores
+//                  A(q,c) = |q|^2 + |c|^2 - 2 q.c   (L2)   or   q.c   (IP)
+//   k_select_mfma  per query: nprobe-th approximate score tau, shortlist {c : A(c) within 2*eps of tau},
+//                  EXACT canonical-order scores for the shortlist only, exact (score, cid) sort.
+// eps bounds |A - canonical| rigorously (standard rounding-error model, n = D, u = 2^-24):
+//   |canonical - s*| <= gamma_n s*  (positive terms),  |A - s*| <= 2 gamma_{n+2} (|q|^2 + |c|^2)
+//   =>  |A - canonical| <= 4 gamma_{n+2} (|q|^2 + |c|^2)   (s* <= 2(|q|^2+|c|^2));  eps uses 6 n u (..), > that.
+// Any true top-nprobe member has canonical <= (largest canonical among the approximate top-nprobe) <= tau+eps,
+// hence A <= tau + 2 eps: it is in the shortlist.  If the shortlist overflows its LDS capacity (many
+// near-equal scores) or a score is not finite, the query falls back to canonical scores for ALL lists.
+#pragma once
+#include "kernels.hpp"
+
+namespace rbq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_rank_mfma(const float* __restrict__ rot, const float* __restrict__ cent,
+                                                   const QueryConsts* __restrict__ consts,
+                                                   const float* __restrict__ cnorm2, uint32_t nq, uint32_t nlist,
+                                                   uint32_t D, float* __restrict__ scores) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 1; // +1: 32 rows of one k column hit 32 distinct banks
+    __shared__ float As[BM][LD];
+    __shared__ float Bs[BN][LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w >> 1, wn = w & 1u;
+    const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    for (uint32_t k0 = 0; k0 < D; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { // 128 rows x 32 floats = 1024 float4 per operand, 4 per thread
+            const uint32_t idx = tid + 256u * i, row = idx >> 3, c4 = (idx & 7u) * 4u, k = k0 + c4;
+            float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
+            if (q0 + row < nq && k < D) av = *reinterpret_cast<const float4*>(rot + (size_t)(q0 + row) * D + k);
+            if (c0 + row < nlist && k < D) bv = *reinterpret_cast<const float4*>(cent + (size_t)(c0 + row) * D + k);
+            As[row][c4] = av.x; As[row][c4 + 1] = av.y; As[row][c4 + 2] = av.z; As[row][c4 + 3] = av.w;
+            Bs[row][c4] = bv.x; Bs[row][c4 + 1] = bv.y; Bs[row][c4 + 2] = bv.z; Bs[row][c4 + 3] = bv.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const uint32_t r = lane & 31u, kx = kk + (lane >> 5);
+            const float a0 = As[wm * 64 + r][kx], a1 = As[wm * 64 + 32 + r][kx];
+            const float b0 = Bs[wn * 64 + r][kx], b1 = Bs[wn * 64 + 32 + r][kx];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t c = c0 + wn * 64 + b * 32 + (lane & 31u);
+            const float cn = (METRIC == 0 && c < nlist) ? cnorm2[c] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t qi = q0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qi < nq && c < nlist) {
+                    const float dot = acc[a][b][r];
+                    float v = dot;
+                    if (METRIC == 0) {
+                        const float qn = consts[qi].qnorm2;
+                        v = fmaf(-2.0f, dot, qn + cn);
+                    }
+                    scores[(size_t)qi * nlist + c] = v;
+                }
+            }
+        }
+}
+
+// Canonical-order score of one (query, list) pair on 2 lanes: lane h owns the reference's accumulators
+// 4h..4h+3 (elements 8t+4h..8t+4h+3, one 16-byte load per step); the final sum adds the eight accumulators
+// in order 0..7 starting from -0.0 (Rust iter().sum()), then the scalar tail.  D % 4 == 0.
+template <int METRIC>
+__device__ __forceinline__ float canon_pair2(const float* qrot, const float* __restrict__ c, uint32_t D, uint32_t h) {
+    const uint32_t Dmain = D & ~7u;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll 4
+    for (uint32_t i = 4 * h; i < Dmain; i += 8) {
+        const float4 cv = *reinterpret_cast<const float4*>(c + i);
+        const float4 qv = *reinterpret_cast<const float4*>(qrot + i);
+        float p0, p1, p2, p3;
+        if (METRIC == 0) {
+            const float d0 = qv.x - cv.x, d1 = qv.y - cv.y, d2 = qv.z - cv.z, d3 = qv.w - cv.w;
+            p0 = d0 * d0; p1 = d1 * d1; p2 = d2 * d2; p3 = d3 * d3;
+        } else {
+            p0 = qv.x * cv.x; p1 = qv.y * cv.y; p2 = qv.z * cv.z; p3 = qv.w * cv.w;
+        }
+        a0 = a0 + p0; a1 = a1 + p1; a2 = a2 + p2; a3 = a3 + p3;
+    }
+    float sum = 0.0f;
+    if (Dmain) {
+        sum = -0.0f;
+        sum = sum + __shfl(a0, 0, 2); sum = sum + __shfl(a1, 0, 2); sum = sum + __shfl(a2, 0, 2); sum = sum + __shfl(a3, 0, 2);
+        sum = sum + __shfl(a0, 1, 2); sum = sum + __shfl(a1, 1, 2); sum = sum + __shfl(a2, 1, 2); sum = sum + __shfl(a3, 1, 2);
+    }
+    for (uint32_t i = Dmain; i < D; ++i) {
+        float p;
+        if (METRIC == 0) {
+            const float d = qrot[i] - c[i];
+            p = d * d;
+        } else {
+            p = qrot[i] * c[i];
+        }
+        sum = sum + p;
+    }
+    return sum;
+}
+
+// dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when row_in_lds)
+__global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_t nlist, uint32_t nprobe,
+                                                          uint32_t cap2, int row_in_lds, int metric, const float* __restrict__ rot,
+                                                          const float* __restrict__ cent, uint32_t D,
+                                                          const QueryConsts* __restrict__ consts, float cnorm2_max,
+                                                          const uint32_t* __restrict__ list_gb0,
+                                                          const uint32_t* __restrict__ list_n,
+                                                          ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
+                                                          uint64_t wl_stride, uint32_t* __restrict__ nstream,
+                                                          unsigned long long* __restrict__ nvec_probed,
+                                                          unsigned long long* __restrict__ prof_total,
+                                                          unsigned int* __restrict__ fallback_count) {
+    extern __shared__ __align__(16) unsigned char smraw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smraw);
+    float* qrot = reinterpret_cast<float*>(smraw + (size_t)cap2 * 8);
+    uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_mask, s_k, s_cnt, s_bad;
+    __shared__ unsigned long long s_nvec;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    float* grow = approx + (size_t)q * nlist;
+    float* sc = grow;
+    if (row_in_lds) { // the approximate row is read ~6 times: keep it in LDS when it fits
+        float* lrow = reinterpret_cast<float*>(part + kThreads);
+        for (uint32_t i = tid; i < nlist; i += kThreads) lrow[i] = grow[i];
+        sc = lrow;
+    }
+
+    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
+    if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
+    __syncthreads();
+
+    // ordered 32-bit key of the approximate score (ascending = better)
+    auto okey = [&](float s) -> uint32_t {
+        int32_t k = total_key(s);
+        if (metric == 1) k = ~k;
+        return (uint32_t)k ^ 0x80000000u;
+    };
+    // 1. tau = nprobe-th best approximate score (value only: 4 radix passes over the 32-bit key)
+    bool all = nprobe >= nlist;
+    if (!all) {
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix, mask = s_mask;
+            for (uint32_t i = tid; i < nlist; i += kThreads) {
+                const float s = sc[i];
+                if (!finite_f(s)) s_bad = 1;
+                const uint32_t key = okey(s);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t k = s_k, cum = 0, b = 0;
+                for (; b < 256; ++b) {
+                    const uint32_t h = hist[b];
+                    if (k < cum + h) break;
+                    cum += h;
+                }
+                s_k = k - cum;
+                s_prefix = prefix | (b << shift);
+                s_mask = mask | (0xffu << shift);
+            }
+            __syncthreads();
+        }
+    }
+    // 2. shortlist: approximate score within 2*eps of tau
+    const QueryConsts qc = consts[q];
+    const float eps = 6.0f * (float)D * 5.9604645e-8f * (qc.qnorm2 + cnorm2_max) * 1.001f;
+    uint32_t cut = 0xffffffffu;
+    if (!all) {
+        // back from ordered key to the score value
+        int32_t k = (int32_t)(s_prefix ^ 0x80000000u);
+        if (metric == 1) k = ~k;
+        const float tau = key_to_float(k);
+        const float lim = metric == 0 ? tau + 2.0f * eps : tau - 2.0f * eps;
+        cut = okey(lim);
+        if (!finite_f(lim)) cut = 0xffffffffu;
+    }
+    for (uint32_t i = tid; i < cap2; i += kThreads) keys[i] = ~0ull;
+    __syncthreads();
+    bool fallback = s_bad != 0;
+    if (!fallback) {
+        for (uint32_t i = tid; i < nlist; i += kThreads) {
+            if (okey(sc[i]) <= cut) {
+                const uint32_t p = atomicAdd(&s_cnt, 1u);
+                if (p < cap2) keys[p] = i; // cid for now; exact key after the canonical pass
+            }
+        }
+        __syncthreads();
+        fallback = s_cnt > cap2 || s_cnt < nprobe;
+    }
+    __syncthreads();
+    const uint32_t l2 = tid & 1u, grp = tid >> 1; // 128 pairs in flight
+    if (!fallback) {
+        // 3. exact canonical scores of the shortlist, exact (score, cid) keys, sort
+        const uint32_t n = s_cnt;
+        for (uint32_t i0 = 0; i0 < n; i0 += kThreads / 2) {
+            const uint32_t i = i0 + grp;
+            uint32_t cid = 0;
+            float s = 0.0f;
+            if (i < n) {
+                cid = (uint32_t)keys[i];
+                const float* c = cent + (size_t)cid * D;
+                s = metric == 0 ? canon_pair2<0>(qrot, c, D, l2) : canon_pair2<1>(qrot, c, D, l2);
+            }
+            if (i < n && l2 == 0) keys[i] = make_key(s, cid, metric);
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= cap2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < cap2; i += kThreads) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint64_t a = keys[i], b = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    } else {
+        // fallback (rare: shortlist overflow or non-finite approximate scores): overwrite this query's row
+        // with canonical scores of EVERY list, then the exact 64-bit (score, cid) radix select of k_select
+        if (tid == 0 && fallback_count) atomicAdd(fallback_count, 1u);
+        float* row = grow;
+        for (uint32_t base = 0; base < nlist; base += kThreads / 2) {
+            const uint32_t cid = base + grp;
+            if (cid < nlist) {
+                const float* c = cent + (size_t)cid * D;
+                const float s = metric == 0 ? canon_pair2<0>(qrot, c, D, l2) : canon_pair2<1>(qrot, c, D, l2);
+                if (l2 == 0) row[cid] = s;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        __shared__ unsigned long long s_prefix64, s_mask64;
+        if (tid == 0) { s_prefix64 = all ? ~0ull : 0ull; s_mask64 = 0; s_k = nprobe - 1; s_cnt = 0; }
+        __syncthreads();
+        if (!all) {
+            for (int pass = 7; pass >= 0; --pass) {
+                const int shift = pass * 8;
+                hist[tid] = 0;
+                __syncthreads();
+                const unsigned long long prefix = s_prefix64, mask = s_mask64;
+                for (uint32_t i = tid; i < nlist; i += kThreads) {
+                    const uint64_t key = make_key(row[i], i, metric);
+                    if ((key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t k = s_k, cum = 0, bb = 0;
+                    for (; bb < 256; ++bb) {
+                        const uint32_t h = hist[bb];
+                        if (k < cum + h) break;
+                        cum += h;
+                    }
+                    s_k = k - cum;
+                    s_prefix64 = prefix | ((unsigned long long)bb << shift);
+                    s_mask64 = mask | (0xffull << shift);
+                }
+                __syncthreads();
+            }
+        }
+        const uint64_t kstar = s_prefix64;
+        for (uint32_t i = tid; i < cap2; i += kThreads) keys[i] = ~0ull;
+        __syncthreads();
+        for (uint32_t i = tid; i < nlist; i += kThreads) {
+            const uint64_t key = make_key(row[i], i, metric);
+            if (key <= kstar) {
+                const uint32_t p = atomicAdd(&s_cnt, 1u);
+                if (p < cap2) keys[p] = key;
+            }
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= cap2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < cap2; i += kThreads) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint64_t a = keys[i], b2 = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b2) == up) { keys[i] = b2; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+
+    // 4. per-probe constants (src/ivf.rs:1850-1857), block counts, work list — as k_select
+    const uint32_t per = (nprobe + kThreads - 1) / kThreads;
+    const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
+    uint32_t local = 0;
+    unsigned long long local_vec = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint64_t key = keys[r];
+        const uint32_t cid = (uint32_t)(key & 0xffffffffu);
+        int32_t k = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+        if (metric == 1) k = ~k;
+        const float s = key_to_float(k);
+        float dist, dot;
+        const float* c = cent + (size_t)cid * D;
+        // L2: score IS the centroid distance; the dot product only feeds the non-finite lower-bound
+        // fallback of the IP metric (src/ivf.rs:2031-2042), so it is not computed here.
+        if (metric == 0) { dist = s; dot = 0.0f; }
+        else { dot = s; dist = canon_l2(qrot, c, D); }
+        ProbeInfo pi;
+        pi.g_add = metric == 0 ? dist : -dot;
+        pi.g_err = sqrtf(dist);
+        pi.dotqc = dot;
+        pi.cid = cid;
+        probe[(size_t)q * nprobe + r] = pi;
+        local += (list_n[cid] + 31u) >> 5;
+        local_vec += list_n[cid];
+    }
+    part[tid] = local;
+    if (local_vec) atomicAdd(&s_nvec, local_vec);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < kThreads; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        nstream[q] = run;
+        nvec_probed[q] = s_nvec;
+        if (prof_total) atomicAdd(prof_total, s_nvec);
+    }
+    __syncthreads();
+    uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t cid = (uint32_t)(keys[r] & 0xffffffffu);
+        const uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
+            WorkItem wi;
+            wi.gblock = gb + b;
+            wi.rank_nvalid = (r << 6) | nv;
+            wl[pos++] = wi;
+        }
+    }
+}
+
+} // namespace rbq

@@ -17,6 +17,7 @@
 #include "rbq.h"
 #include "kernels.hpp"
 #include "scan.hpp"
+#include "rank_mfma.hpp"
 
 using namespace rbq;
 
@@ -83,7 +84,9 @@ struct rbq_index {
     float fac = 1.0f;
     // device arrays
     void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
-         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr;
+         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr;
+    float cnorm2_max = 0.0f;
+    bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
     // host
     std::vector<uint32_t> h_list_n;
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
@@ -101,7 +104,7 @@ void free_index(rbq_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (void* p : {ix->d_rot_blob, ix->d_centroids, ix->d_blocks, ix->d_ids, ix->d_ex, ix->d_fadd_ex, ix->d_fres_ex,
-                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum})
+                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum, ix->d_cnorm2, ix->d_fallbacks})
         if (p) (void)hipFree(p);
     for (Workspace* w : ix->pool) { w->release(); delete w; }
     for (auto& sp : ix->prof)
@@ -294,6 +297,22 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     UP(d_fadd_ex, fa); UP(d_fres_ex, fr); UP(d_list_gb0, gb0); UP(d_list_n, ln);
     { std::vector<unsigned long long> z(1, 0); UP(d_prof_total, z); }
     UP(d_bsum, bsum);
+    {
+        std::vector<float> cn(ix->n_lists);
+        double mx = 0;
+        for (uint64_t c = 0; c < ix->n_lists; ++c) {
+            double a = 0;
+            for (uint32_t i = 0; i < D; ++i) a += (double)cent[c * D + i] * (double)cent[c * D + i];
+            cn[c] = (float)a;
+            if (std::isfinite(a)) mx = std::max(mx, a);
+        }
+        ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
+        UP(d_cnorm2, cn);
+        std::vector<unsigned int> z(1, 0);
+        UP(d_fallbacks, z);
+        const char* e = std::getenv("RBQ_EXACT_RANK");
+        ix->exact_rank = e && e[0] == '1';
+    }
 #undef UP
     *out = ix;
     return RBQ_OK;
@@ -378,26 +397,57 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
                            (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p);
         HIP_TRY(hipGetLastError());
     }
-    {
-        ProfScope ps(ix, 1, stream);
-        dim3 grid((nlist + 31) / 32, (uint32_t)((nq + 31) / 32));
-        if (ix->metric == 0)
-            hipLaunchKernelGGL(k_rank_scores<0>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
-                               (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
-        else
-            hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
-                               (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
-        HIP_TRY(hipGetLastError());
-    }
-    {
-        ProfScope ps(ix, 2, stream);
-        const size_t lds = (size_t)np2 * 8 + (size_t)D * 4 + kThreads * 4;
-        hipLaunchKernelGGL(k_select, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (const float*)w->scores.p, nlist, nprobe,
-                           np2, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
-                           (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
-                           (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
-                           ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr);
-        HIP_TRY(hipGetLastError());
+    if (ix->exact_rank) {
+        {
+            ProfScope ps(ix, 1, stream);
+            dim3 grid((nlist + 31) / 32, (uint32_t)((nq + 31) / 32));
+            if (ix->metric == 0)
+                hipLaunchKernelGGL(k_rank_scores<0>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
+                                   (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
+            else
+                hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
+                                   (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
+            HIP_TRY(hipGetLastError());
+        }
+        {
+            ProfScope ps(ix, 2, stream);
+            const size_t lds = (size_t)np2 * 8 + (size_t)D * 4 + kThreads * 4;
+            hipLaunchKernelGGL(k_select, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (const float*)w->scores.p, nlist, nprobe,
+                               np2, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
+                               (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
+                               (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
+                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        {
+            ProfScope ps(ix, 1, stream); // approximate scores: one f32 MFMA GEMM
+            dim3 grid((nlist + 127) / 128, (uint32_t)((nq + 127) / 128));
+            if (ix->metric == 0)
+                hipLaunchKernelGGL(k_rank_mfma<0>, grid, dim3(256), 0, stream, (const float*)w->rot.p,
+                                   (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,
+                                   (uint32_t)nq, nlist, D, (float*)w->scores.p);
+            else
+                hipLaunchKernelGGL(k_rank_mfma<1>, grid, dim3(256), 0, stream, (const float*)w->rot.p,
+                                   (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,
+                                   (uint32_t)nq, nlist, D, (float*)w->scores.p);
+            HIP_TRY(hipGetLastError());
+        }
+        {
+            ProfScope ps(ix, 2, stream); // shortlist + exact canonical scores + exact select
+            const uint32_t cap2 = std::max<uint32_t>(64u, next_pow2(2 * nprobe));
+            const int row_in_lds = (size_t)nlist * 4 <= 65536 ? 1 : 0;
+            const size_t lds = (size_t)cap2 * 8 + (size_t)D * 4 + kThreads * 4 + (row_in_lds ? (size_t)nlist * 4 : 0);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            HIP_TRY(e);
+            hipLaunchKernelGGL(k_select_mfma, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (float*)w->scores.p, nlist, nprobe,
+                               cap2, row_in_lds, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
+                               (const QueryConsts*)w->consts.p, ix->cnorm2_max, (const uint32_t*)ix->d_list_gb0,
+                               (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p, (WorkItem*)w->wl.p, wl_stride,
+                               (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
+                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr, (unsigned int*)ix->d_fallbacks);
+            HIP_TRY(hipGetLastError());
+        }
     }
     {
         ProfScope ps(ix, 3, stream);
@@ -714,5 +764,13 @@ double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* la
     return ix->prof[s].launches ? ix->prof[s].ms / (double)ix->prof[s].launches : 0.0;
 }
 uint64_t rbq_profile_scan_bytes(const rbq_index* ix) { return ix ? ix->prof_scan_bytes : 0; }
+uint64_t rbq_debug_rank_fallbacks(const rbq_index* ix) {
+    if (!ix) return 0;
+    unsigned int v = 0;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(&v, ix->d_fallbacks, 4, hipMemcpyDeviceToHost);
+    return v;
+}
 
 } // extern "C"

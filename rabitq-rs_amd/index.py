@@ -44,6 +44,8 @@ def lib():
         L.rbq_profile_stage_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
         L.rbq_profile_scan_bytes.restype = C.c_uint64
         L.rbq_profile_scan_bytes.argtypes = [vp]
+        L.rbq_debug_rank_fallbacks.restype = C.c_uint64
+        L.rbq_debug_rank_fallbacks.argtypes = [vp]
         L.rbq_strerror.restype = C.c_char_p
         L.rbq_strerror.argtypes = [C.c_int]
         L.rbq_last_error_detail.restype = C.c_int
@@ -194,6 +196,9 @@ class IvfRabitqIndex:
         n = C.c_uint64()
         ms = lib().rbq_profile_stage_ms(self._h, name.encode(), C.byref(n))
         return ms, n.value
+
+    def rank_fallbacks(self):
+        return lib().rbq_debug_rank_fallbacks(self._h)
 
     def profile_scan_bytes(self):
         return lib().rbq_profile_scan_bytes(self._h)
