@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
                                                           uint64_t wl_stride, uint32_t* __restrict__ nstream,
                                                           unsigned long long* __restrict__ nvec_probed,
                                                           unsigned long long* __restrict__ prof_total,
-                                                          unsigned int* __restrict__ fallback_count) {
+                                                          unsigned int* __restrict__ fallback_count, int force_fallback) {
     extern __shared__ __align__(16) unsigned char smraw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smraw);
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)cap2 * 8);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     }
     for (uint32_t i = tid; i < cap2; i += kThreads) keys[i] = ~0ull;
     __syncthreads();
-    bool fallback = s_bad != 0;
+    bool fallback = s_bad != 0 || force_fallback != 0;
     if (!fallback) {
         for (uint32_t i = tid; i < nlist; i += kThreads) {
             if (okey(sc[i]) <= cut) {

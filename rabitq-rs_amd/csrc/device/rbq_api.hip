@@ -86,6 +86,7 @@ struct rbq_index {
     void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
          *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr;
     float cnorm2_max = 0.0f;
+    bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
     bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
     // host
     std::vector<uint32_t> h_list_n;
@@ -312,6 +313,8 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
         UP(d_fallbacks, z);
         const char* e = std::getenv("RBQ_EXACT_RANK");
         ix->exact_rank = e && e[0] == '1';
+        const char* f = std::getenv("RBQ_FORCE_RANK_FALLBACK");
+        ix->force_rank_fallback = f && f[0] == '1';
     }
 #undef UP
     *out = ix;
@@ -445,7 +448,8 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
                                (const QueryConsts*)w->consts.p, ix->cnorm2_max, (const uint32_t*)ix->d_list_gb0,
                                (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p, (WorkItem*)w->wl.p, wl_stride,
                                (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
-                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr, (unsigned int*)ix->d_fallbacks);
+                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr, (unsigned int*)ix->d_fallbacks,
+                               ix->force_rank_fallback ? 1 : 0);
             HIP_TRY(hipGetLastError());
         }
     }

@@ -61,6 +61,85 @@ def test_search_matches_oracle(n, dim, nlist, bits, metric, rot, nq, top_k, npro
     idx.close()
 
 
+def test_filter_without_diag_uses_block_bound():
+    """Filtered search without diagnostics keeps the block-level lower bound enabled (it is switched off
+    only when per-candidate filter tests are needed for exact diag counters)."""
+    data, built = build_index(n=6000, dim=128, nlist=48, total_bits=7)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(32, 128, 12, 5)
+    allowed = np.arange(0, 6000, 2)
+    nbits = 6000
+    words = np.zeros((nbits + 31) // 32, np.uint32)
+    np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+    rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, 10, 24, words, nbits)
+    ids, sc, cnt, _ = idx.batch_search_raw(q, rq.SearchParams(10, 24), words, nbits, want_diag=False)
+    assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)
+    np.testing.assert_allclose(sc, osc, rtol=RTOL)
+    idx.close()
+
+
+def test_duplicate_vectors_exact_ties():
+    """Identical vectors produce identical codes, factors and distances: the heap's tie handling (Rust std
+    BinaryHeap sift order, restated in oracle and kernel) must agree element for element."""
+    base = make_dataset(700, 64, 4, 21)
+    data = np.concatenate([base, base, base[:300]], axis=0)
+    _, built = build_index(nlist=12, total_bits=7, data=data, dim=64)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    _compare(built, idx, base[:48], 10, 6)
+    _compare(built, idx, base[:16], 3, 12)
+    idx.close()
+
+
+def test_u16_accumulator_wrap_dim1536():
+    """D > 1028: the u8-LUT sum can exceed 65535 and wraps exactly like the reference's u16 lanes
+    (src/simd.rs:1016-1110); the block bound must switch itself off (amax > 65535)."""
+    data, built = build_index(n=1500, dim=1536, nlist=8, total_bits=7, seed=5)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(16, 1536, 2, 6)
+    _compare(built, idx, q, 10, 4)
+    idx.close()
+
+
+def test_rank_fallback_path_matches(monkeypatch):
+    """The all-lists canonical fallback of the MFMA shortlist selector returns the same probes."""
+    data, built = build_index(n=5000, dim=128, nlist=64, total_bits=7)
+    q = make_dataset(64, 128, 16, 9)
+    monkeypatch.setenv("RBQ_FORCE_RANK_FALLBACK", "1")
+    idx = rq.IvfRabitqIndex.from_built(built)
+    _compare(built, idx, q, 10, 16)
+    assert idx.rank_fallbacks() >= 64
+    idx.close()
+    monkeypatch.delenv("RBQ_FORCE_RANK_FALLBACK")
+    monkeypatch.setenv("RBQ_EXACT_RANK", "1")
+    idx = rq.IvfRabitqIndex.from_built(built)
+    _compare(built, idx, q, 10, 16)
+    idx.close()
+
+
+def test_near_duplicate_centroids_overflow_shortlist():
+    """Many (near-)equal centroid scores overflow the shortlist window and must take the exact fallback."""
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((40, 64)).astype(np.float32)
+    cent = np.repeat(base, 8, axis=0) + 1e-6 * rng.standard_normal((320, 64)).astype(np.float32)
+    data = cent[rng.integers(0, 320, 6000)] + 0.05 * rng.standard_normal((6000, 64)).astype(np.float32)
+    assign = np.argmin(((data[:, None, :] - cent[None, :, :]) ** 2).sum(-1), axis=1).astype(np.uint32)
+    built = rq.builder.train_with_clusters(data, cent, assign, 7, 0, 1, 11, True)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    _compare(built, idx, data[:64], 10, 20)
+    idx.close()
+
+
+def test_host_chunking_large_nq():
+    """rbq_search_batch processes 16384 queries per device pass: cross a chunk boundary."""
+    data, built = build_index(n=1200, dim=64, nlist=8, total_bits=3)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(16384 + 300, 64, 2, 17)
+    ids, sc, cnt, _ = idx.batch_search_raw(q, rq.SearchParams(5, 3))
+    rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, 5, 3)
+    assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)
+    idx.close()
+
+
 def test_nprobe_clamp_and_small_counts():
     data, built = build_index(n=300, dim=64, nlist=8, total_bits=7)
     idx = rq.IvfRabitqIndex.from_built(built)
