@@ -86,6 +86,7 @@ struct rbq_index {
     void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
          *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr;
     float cnorm2_max = 0.0f;
+    bool no_block_bound = false; // rbq_debug_set_option("block_bound", 0)
     bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
     bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
     // host
@@ -464,6 +465,7 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
         P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
         P.D = D; P.Dc = Dc; P.nprobe = nprobe; P.top_k = top_k; P.metric = ix->metric; P.ex_bits = ix->ex_bits;
+        P.no_block_bound = ix->no_block_bound ? 1u : 0u;
         const size_t lds = scan_lds_bytes(Dc, D, ix->ex_bits, top_k);
         hipError_t e;
         if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
@@ -768,6 +770,13 @@ double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* la
     return ix->prof[s].launches ? ix->prof[s].ms / (double)ix->prof[s].launches : 0.0;
 }
 uint64_t rbq_profile_scan_bytes(const rbq_index* ix) { return ix ? ix->prof_scan_bytes : 0; }
+int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
+    if (!ix || !name) return RBQ_INVALID_CONFIG;
+    if (!std::strcmp(name, "block_bound")) { ix->no_block_bound = value == 0; return RBQ_OK; }
+    if (!std::strcmp(name, "exact_rank")) { ix->exact_rank = value != 0; return RBQ_OK; }
+    if (!std::strcmp(name, "force_rank_fallback")) { ix->force_rank_fallback = value != 0; return RBQ_OK; }
+    return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
+}
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* ix) {
     if (!ix) return 0;
     unsigned int v = 0;

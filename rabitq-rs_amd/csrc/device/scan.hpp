@@ -51,6 +51,7 @@ struct ScanParams {
     uint32_t* out_counts;
     unsigned long long* diag; // [nq][3] or null
     uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
+    uint32_t no_block_bound; // diagnostic: stream every probed block (measures the pure streaming rate)
 };
 
 #ifndef RBQ_SCAN_WAVES
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     // larger) threshold for every lane, the reference skips all of these candidates too and the block's
     // codes are never read.  Disabled when accu could wrap (amax > 65535) and when filtered diagnostics need
     // per-candidate filter tests.
-    const bool bound_ok = qc.amax <= 65535.0f && !(P.filter && P.diag);
+    const bool bound_ok = qc.amax <= 65535.0f && !(P.filter && P.diag) && !P.no_block_bound;
     auto lane_prunable = [&](const WorkItem& w, const Meta& m, float T) -> bool {
         float d0, d1;
         const float a = lb_of(m, qc.amin, d0, d1), b = lb_of(m, qc.amax, d0, d1);

@@ -46,6 +46,8 @@ def lib():
         L.rbq_profile_scan_bytes.argtypes = [vp]
         L.rbq_debug_rank_fallbacks.restype = C.c_uint64
         L.rbq_debug_rank_fallbacks.argtypes = [vp]
+        L.rbq_debug_set_option.restype = C.c_int
+        L.rbq_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.rbq_strerror.restype = C.c_char_p
         L.rbq_strerror.argtypes = [C.c_int]
         L.rbq_last_error_detail.restype = C.c_int
@@ -196,6 +198,9 @@ class IvfRabitqIndex:
         n = C.c_uint64()
         ms = lib().rbq_profile_stage_ms(self._h, name.encode(), C.byref(n))
         return ms, n.value
+
+    def set_option(self, name, value):
+        _check(lib().rbq_debug_set_option(self._h, name.encode(), int(value)))
 
     def rank_fallbacks(self):
         return lib().rbq_debug_rank_fallbacks(self._h)
