@@ -124,10 +124,11 @@ int rbq_search_batch(const rbq_index* idx, const float* queries, uint64_t nq,
                      uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
                      rbq_diag* diag);
 
-/* Same operation on DEVICE pointers (queries and outputs already in HBM of the
- * index's device), enqueued on `hip_stream` (a hipStream_t passed as void*,
- * NULL = default stream); returns once the batch has completed on that stream
- * (the per-call workspace is recycled on return). d_filter_words may be NULL. d_diag is NULL or [nq] rbq_diag in device memory. */
+/* Same operation on DEVICE pointers (queries and outputs already in HBM of the index's device), ENQUEUED on
+ * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returning without host
+ * synchronisation: results are valid once the stream reaches this point. Each stream gets its own scratch
+ * workspace inside the handle; issue calls for one stream from one host thread at a time.
+ * d_filter_words may be NULL. d_diag is NULL or [nq] rbq_diag in device memory. */
 int rbq_search_batch_device(const rbq_index* idx, const float* d_queries, uint64_t nq,
                             uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
                             const uint32_t* d_filter_words, uint64_t filter_nbits,

@@ -20,27 +20,29 @@ namespace rbq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int METRIC>
+// TW = 2: 128x128 tile (64x64 per wave, 4 MFMA per k-pair); TW = 1: 64x64 tile (32x32 per wave) for small
+// problems where 128x128 tiles would leave most CUs idle.
+template <int METRIC, int TW>
 __global__ __launch_bounds__(256) void k_rank_mfma(const float* __restrict__ rot, const float* __restrict__ cent,
                                                    const QueryConsts* __restrict__ consts,
                                                    const float* __restrict__ cnorm2, uint32_t nq, uint32_t nlist,
                                                    uint32_t D, float* __restrict__ scores) {
-    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 1; // +1: 32 rows of one k column hit 32 distinct banks
+    constexpr int BM = 64 * TW, BN = 64 * TW, BK = 32, LD = BK + 1; // +1: 32 rows of one k column hit 32 distinct banks
     __shared__ float As[BM][LD];
     __shared__ float Bs[BN][LD];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w >> 1, wn = w & 1u;
     const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BN;
-    f32x16 acc[2][2];
+    f32x16 acc[TW][TW];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TW; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     for (uint32_t k0 = 0; k0 < D; k0 += BK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { // 128 rows x 32 floats = 1024 float4 per operand, 4 per thread
+        for (int i = 0; i < 2 * TW; ++i) { // BM rows x 32 floats = BM*8 float4 per operand
             const uint32_t idx = tid + 256u * i, row = idx >> 3, c4 = (idx & 7u) * 4u, k = k0 + c4;
             float4 av = make_float4(0, 0, 0, 0), bv = make_float4(0, 0, 0, 0);
             if (q0 + row < nq && k < D) av = *reinterpret_cast<const float4*>(rot + (size_t)(q0 + row) * D + k);
@@ -52,25 +54,30 @@ __global__ __launch_bounds__(256) void k_rank_mfma(const float* __restrict__ rot
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const uint32_t r = lane & 31u, kx = kk + (lane >> 5);
-            const float a0 = As[wm * 64 + r][kx], a1 = As[wm * 64 + 32 + r][kx];
-            const float b0 = Bs[wn * 64 + r][kx], b1 = Bs[wn * 64 + 32 + r][kx];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TW], bv[TW];
+#pragma unroll
+            for (int a = 0; a < TW; ++a) {
+                av[a] = As[wm * 32 * TW + a * 32 + r][kx];
+                bv[a] = Bs[wn * 32 * TW + a * 32 + r][kx];
+            }
+#pragma unroll
+            for (int a = 0; a < TW; ++a)
+#pragma unroll
+                for (int b = 0; b < TW; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
     }
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TW; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint32_t c = c0 + wn * 64 + b * 32 + (lane & 31u);
+        for (int b = 0; b < TW; ++b) {
+            const uint32_t c = c0 + wn * 32 * TW + b * 32 + (lane & 31u);
             const float cn = (METRIC == 0 && c < nlist) ? cnorm2[c] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t qi = q0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t qi = q0 + wm * 32 * TW + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (qi < nq && c < nlist) {
                     const float dot = acc[a][b][r];
                     float v = dot;
@@ -313,7 +320,23 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
             }
     }
 
-    // 4. per-probe constants (src/ivf.rs:1850-1857), block counts, work list — as k_select
+    // 4. per-probe constants (src/ivf.rs:1850-1857), block counts, work list — as k_select.
+    // IP needs the canonical centroid distance of every probed list as well (g_error): computed by the same
+    // 2-lane groups, 128 lists per round, and parked in the (now free) tail of the key buffer.
+    float* dist_ip = reinterpret_cast<float*>(keys + nprobe); // cap2 >= 2*nprobe: room for nprobe floats
+    if (metric == 1) {
+        for (uint32_t i0 = 0; i0 < nprobe; i0 += kThreads / 2) {
+            const uint32_t r = i0 + grp;
+            float d = 0.0f;
+            if (r < nprobe) {
+                const uint32_t cid = (uint32_t)(keys[r] & 0xffffffffu);
+                d = canon_pair2<0>(qrot, cent + (size_t)cid * D, D, l2);
+            }
+            __syncthreads(); // all reads of keys[r] of this round done before the tail is written
+            if (r < nprobe && l2 == 0) dist_ip[r] = d;
+        }
+        __syncthreads();
+    }
     const uint32_t per = (nprobe + kThreads - 1) / kThreads;
     const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
     uint32_t local = 0;
@@ -325,11 +348,10 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
         if (metric == 1) k = ~k;
         const float s = key_to_float(k);
         float dist, dot;
-        const float* c = cent + (size_t)cid * D;
         // L2: score IS the centroid distance; the dot product only feeds the non-finite lower-bound
         // fallback of the IP metric (src/ivf.rs:2031-2042), so it is not computed here.
         if (metric == 0) { dist = s; dot = 0.0f; }
-        else { dot = s; dist = canon_l2(qrot, c, D); }
+        else { dot = s; dist = dist_ip[r]; }
         ProbeInfo pi;
         pi.g_add = metric == 0 ? dist : -dot;
         pi.g_err = sqrtf(dist);

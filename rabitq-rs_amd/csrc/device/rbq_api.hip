@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -94,6 +95,7 @@ struct rbq_index {
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
     std::mutex mu;
     std::vector<Workspace*> pool;
+    std::map<hipStream_t, Workspace*> stream_ws; // rbq_search_batch_device: one workspace per caller stream
     // profiling
     bool profiling = false;
     StageProf prof[4]; // prep, rank, select, scan
@@ -109,6 +111,7 @@ void free_index(rbq_index* ix) {
                     ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum, ix->d_cnorm2, ix->d_fallbacks})
         if (p) (void)hipFree(p);
     for (Workspace* w : ix->pool) { w->release(); delete w; }
+    for (auto& kv : ix->stream_ws) { kv.second->release(); delete kv.second; }
     for (auto& sp : ix->prof)
         for (auto& e : sp.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete ix;
@@ -355,8 +358,10 @@ struct ProfScope {
 
 template <int DT, int EX>
 hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    if (lds > 48 * 1024) { // default dynamic-LDS limit covers the common case; raising it is a driver call
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
     return hipGetLastError();
 }
@@ -426,15 +431,16 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
     } else {
         {
             ProfScope ps(ix, 1, stream); // approximate scores: one f32 MFMA GEMM
-            dim3 grid((nlist + 127) / 128, (uint32_t)((nq + 127) / 128));
-            if (ix->metric == 0)
-                hipLaunchKernelGGL(k_rank_mfma<0>, grid, dim3(256), 0, stream, (const float*)w->rot.p,
-                                   (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,
-                                   (uint32_t)nq, nlist, D, (float*)w->scores.p);
-            else
-                hipLaunchKernelGGL(k_rank_mfma<1>, grid, dim3(256), 0, stream, (const float*)w->rot.p,
-                                   (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,
-                                   (uint32_t)nq, nlist, D, (float*)w->scores.p);
+            const bool big = (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
+            const uint32_t T = big ? 128u : 64u;
+            dim3 grid((nlist + T - 1) / T, (uint32_t)((nq + T - 1) / T));
+#define RBQ_LAUNCH_RANK(M, TW)                                                                                         \
+    hipLaunchKernelGGL((k_rank_mfma<M, TW>), grid, dim3(256), 0, stream, (const float*)w->rot.p,                       \
+                       (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,   \
+                       (uint32_t)nq, nlist, D, (float*)w->scores.p)
+            if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANK(0, 2); else RBQ_LAUNCH_RANK(0, 1); }
+            else { if (big) RBQ_LAUNCH_RANK(1, 2); else RBQ_LAUNCH_RANK(1, 1); }
+#undef RBQ_LAUNCH_RANK
             HIP_TRY(hipGetLastError());
         }
         {
@@ -442,8 +448,8 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             const uint32_t cap2 = std::max<uint32_t>(64u, next_pow2(2 * nprobe));
             const int row_in_lds = (size_t)nlist * 4 <= 65536 ? 1 : 0;
             const size_t lds = (size_t)cap2 * 8 + (size_t)D * 4 + kThreads * 4 + (row_in_lds ? (size_t)nlist * 4 : 0);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            HIP_TRY(e);
+            if (lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_select_mfma, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (float*)w->scores.p, nlist, nprobe,
                                cap2, row_in_lds, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
                                (const QueryConsts*)w->consts.p, ix->cnorm2_max, (const uint32_t*)ix->d_list_gb0,
@@ -664,17 +670,17 @@ int rbq_search_batch_device(const rbq_index* cix, const float* d_queries, uint64
         HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, s));
         return RBQ_OK;
     }
-    Workspace* w = take_ws(ix);
-    if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
-    rc = search_device(ix, w, d_queries, nq, top_k, nprobe, d_filter_words, filter_nbits, d_out_ids, d_out_scores,
-                       d_out_counts, d_diag, s);
-    // workspace buffers stay referenced by the enqueued kernels: hand the workspace back only after
-    // the caller's stream has drained them.
-    hipError_t e = hipStreamSynchronize(s);
-    give_ws(ix, w);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(RBQ_DEVICE, std::string("stream sync: ") + hipGetErrorString(e));
-    return RBQ_OK;
+    // One workspace per caller stream, never handed to anyone else: successive calls on the same stream are
+    // stream-ordered, so their kernels may share the scratch buffers without any host synchronisation.
+    Workspace* w;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        Workspace*& slot = ix->stream_ws[s];
+        if (!slot) slot = new Workspace();
+        w = slot;
+    }
+    return search_device(ix, w, d_queries, nq, top_k, nprobe, d_filter_words, filter_nbits, d_out_ids, d_out_scores,
+                         d_out_counts, d_diag, s);
 }
 
 int rbq_search_batch(const rbq_index* cix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
