@@ -40,6 +40,9 @@ extern "C" {
 #define RBQ_METRIC_IP 1
 #define RBQ_ROTATOR_MATRIX 0       /* RotatorType, src/rotation.rs:10-15 */
 #define RBQ_ROTATOR_FHT_KAC 1
+#define RBQ_ROTATOR_NONE 2         /* no query-time rotation: MSTG posting lists (src/mstg/posting_list.rs:66-101)
+                                      are quantised on raw residuals; padded_dim == dim, rotator_len == 0.
+                                      Not a tag of the RBQ1 format (rbq_index_load_rbq1 rejects it). */
 
 /* FASTSCAN_BATCH_SIZE, src/simd.rs:768 */
 #define RBQ_BATCH 32
@@ -123,6 +126,21 @@ int rbq_search_batch(const rbq_index* idx, const float* queries, uint64_t nq,
                      const uint32_t* filter_words, uint64_t filter_nbits,
                      uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
                      rbq_diag* diag);
+
+/* MSTG posting-list scan: the caller (MstgIndex::search, src/mstg/index.rs:149-213) has
+ * already chosen the posting lists of each query (HNSW centroid search + dynamic pruning stay on the
+ * CPU); this scans them like search_posting_list_fastscan (src/mstg/index.rs:216-330) — binary FastScan
+ * estimate only, f_error/g_error = 0, non-finite estimates dropped, L2 estimates clamped to >= 0 — and
+ * keeps the top_k smallest distances like the partial sort of MstgIndex::search (:185-205; ties there
+ * are unordered, here the earlier candidate in (list order, vector order) wins).
+ *
+ * list_ids:    [nq][max_lists] posting-list (cluster) ids per query, scanned in the given order
+ * list_counts: [nq]            number of valid entries of each row (<= max_lists)
+ * out_*:       as rbq_search_batch; out_scores are distances (ascending) for both metrics
+ * The index must have been created with rotator = RBQ_ROTATOR_NONE. */
+int rbq_posting_scan_batch(const rbq_index* idx, const float* queries, uint64_t nq, uint32_t query_dim,
+                           uint32_t top_k, const uint32_t* list_ids, const uint32_t* list_counts,
+                           uint32_t max_lists, uint64_t* out_ids, float* out_scores, uint32_t* out_counts);
 
 /* Same operation on DEVICE pointers (queries and outputs already in HBM of the index's device), ENQUEUED on
  * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returning without host

@@ -61,6 +61,9 @@ def lib():
         L.ref_num_threads.restype = C.c_int
         L.ref_search_naive.restype = C.c_int
         L.ref_search_naive.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+        L.ref_posting_scan_batch.restype = C.c_int
+        L.ref_posting_scan_batch.argtypes = [vp, vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32,
+                                             vp, vp, vp, C.c_int]
         _LIB = L
     return _LIB
 
@@ -134,3 +137,17 @@ def select_probes(built, rq, nprobe):
     out = np.empty(built.n_lists, np.uint32)
     n = lib().ref_select_probes(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(rq), nprobe, _p(out))
     return out[:n].copy()
+
+
+def posting_scan_batch(built, queries, top_k, list_ids, list_counts, nthreads=0):
+    """Oracle MSTG posting-list scan. list_ids: [nq, max_lists] u32, list_counts: [nq] u32."""
+    q = np.ascontiguousarray(queries, dtype=np.float32)
+    li = np.ascontiguousarray(list_ids, dtype=np.uint32)
+    lc = np.ascontiguousarray(list_counts, dtype=np.uint32)
+    nq, qd = q.shape
+    ids = np.full((nq, top_k), np.iinfo(np.uint64).max, np.uint64)
+    scores = np.full((nq, top_k), np.nan, np.float32)
+    counts = np.zeros(nq, np.uint32)
+    rc = lib().ref_posting_scan_batch(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(q), nq, qd, top_k, _p(li), _p(lc),
+                                      li.shape[1], _p(ids), _p(scores), _p(counts), nthreads)
+    return rc, ids, scores, counts

@@ -212,6 +212,8 @@ void ref_matrix_rotate(uint32_t dim, uint32_t D, const float* matrix, const floa
 void ref_rotate(const rbq_header* h, const float* in, float* out) {
     if (h->rotator == RBQ_ROTATOR_FHT_KAC)
         ref_fht_kac_rotate(h->dim, h->padded_dim, h->rotator_blob, in, out);
+    else if (h->rotator == RBQ_ROTATOR_NONE)
+        memcpy(out, in, sizeof(float) * h->dim);
     else
         ref_matrix_rotate(h->dim, h->padded_dim, (const float*)h->rotator_blob, in, out);
 }
@@ -859,4 +861,92 @@ int ref_search_naive(const rbq_header* h, const rbq_list_view* lists, const floa
     *out_count = (uint32_t)k;
     free(cand); free(vb); free(cids); free(rq);
     return RBQ_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* MSTG posting-list scan: search_posting_list_fastscan,        */
+/* src/mstg/index.rs:216-330, + the top-k partial sort of MstgIndex::search,  */
+/* :185-205.  No query rotation (QueryContext::new takes the raw query,       */
+/* src/fastscan.rs:159-176); f_error row and g_error are zero; non-finite     */
+/* estimates are dropped; L2 estimates are clamped to >= 0.  The reference's  */
+/* select_nth_unstable/sort_unstable leave ties unordered; this restatement   */
+/* breaks them by (list order, vector order).                                  */
+/* ------------------------------------------------------------------------- */
+int ref_posting_scan(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
+                     uint32_t top_k, const uint32_t* list_ids, uint32_t n_sel,
+                     uint64_t* out_ids, float* out_scores, uint32_t* out_count) {
+    *out_count = 0;
+    if (query_dim != h->dim || h->dim != h->padded_dim) return RBQ_DIMENSION_MISMATCH;
+    size_t D = h->padded_dim, stride = D * 4 + 384;
+    if (D > 2048 || D % 16) return RBQ_INVALID_CONFIG;
+    for (uint32_t i = 0; i < top_k; ++i) { out_ids[i] = UINT64_MAX; out_scores[i] = NAN; }
+    uint8_t* lut8 = (uint8_t*)malloc(D * 4);
+    float delta, sum_vl;
+    ref_query_lut(query, D, lut8, &delta, &sum_vl);
+    float sum_q = -0.0f;
+    for (size_t i = 0; i < D; ++i) sum_q = sum_q + query[i];
+    const float k1x = -0.5f * sum_q;
+    size_t cap = 0;
+    for (uint32_t r = 0; r < n_sel; ++r) if (list_ids[r] < h->n_lists) cap += lists[list_ids[r]].n;
+    naive_cand* cand = (naive_cand*)malloc(sizeof(naive_cand) * (cap ? cap : 1));
+    size_t nc = 0;
+    float zeros[32];
+    memset(zeros, 0, sizeof zeros);
+    for (uint32_t r = 0; r < n_sel; ++r) {
+        if (list_ids[r] >= h->n_lists) continue;
+        const rbq_list_view* pl = &lists[list_ids[r]];
+        if (pl->n == 0) continue;
+        float g_add = h->metric == RBQ_METRIC_L2 ? ref_l2_distance_sqr(query, pl->centroid, D) : -ref_dot(query, pl->centroid, D);
+        size_t nb = (pl->n + 31) / 32;
+        for (size_t b = 0; b < nb; ++b) {
+            const uint8_t* rec = pl->batch_data + b * stride;
+            const float* f_add = (const float*)(rec + D * 4);
+            const float* f_rescale = f_add + 32;
+            uint16_t accu[32];
+            float ip[32], est[32], lb[32];
+            ref_accumulate_batch(rec, lut8, D, accu);
+            ref_compute_batch_distances(accu, delta, sum_vl, f_add, f_rescale, zeros, g_add, 0.0f, k1x, ip, est, lb);
+            size_t start = b * 32, end = start + 32 < pl->n ? start + 32 : pl->n;
+            for (size_t gi = start; gi < end; ++gi) {
+                float d = est[gi - start];
+                if (!isfinite(d)) continue;
+                if (h->metric == RBQ_METRIC_L2 && !(d > 0.0f)) d = 0.0f; /* distance.max(0.0) */
+                cand[nc].id = pl->ids[gi];
+                cand[nc].score = d;
+                cand[nc].seq = nc;
+                ++nc;
+            }
+        }
+    }
+    g_naive_desc = 0;
+    qsort(cand, nc, sizeof(naive_cand), cmp_naive);
+    size_t k = top_k < nc ? top_k : nc;
+    for (size_t i = 0; i < k; ++i) { out_ids[i] = cand[i].id; out_scores[i] = cand[i].score; }
+    *out_count = (uint32_t)k;
+    free(cand); free(lut8);
+    return RBQ_OK;
+}
+
+int ref_posting_scan_batch(const rbq_header* h, const rbq_list_view* lists, const float* queries, uint64_t nq,
+                           uint32_t query_dim, uint32_t top_k, const uint32_t* list_ids, const uint32_t* list_counts,
+                           uint32_t max_lists, uint64_t* out_ids, float* out_scores, uint32_t* out_counts, int nthreads) {
+    int rc_all = RBQ_OK;
+    ref_simd_level();
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t q = 0; q < (int64_t)nq; ++q) {
+        uint32_t n = list_counts[q] < max_lists ? list_counts[q] : max_lists;
+        int rc = ref_posting_scan(h, lists, queries + (size_t)q * query_dim, query_dim, top_k,
+                                  list_ids + (size_t)q * max_lists, n, out_ids + (size_t)q * top_k,
+                                  out_scores + (size_t)q * top_k, out_counts + q);
+        if (rc != RBQ_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            rc_all = rc;
+        }
+    }
+    return rc_all;
 }

@@ -54,6 +54,13 @@ int      ref_num_threads(void);
 int      ref_search_naive(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
                           uint32_t top_k, uint32_t nprobe, uint64_t* out_ids, float* out_scores, uint32_t* out_count);
 
+int      ref_posting_scan(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
+                          uint32_t top_k, const uint32_t* list_ids, uint32_t n_sel,
+                          uint64_t* out_ids, float* out_scores, uint32_t* out_count);
+int      ref_posting_scan_batch(const rbq_header* h, const rbq_list_view* lists, const float* queries, uint64_t nq,
+                                uint32_t query_dim, uint32_t top_k, const uint32_t* list_ids, const uint32_t* list_counts,
+                                uint32_t max_lists, uint64_t* out_ids, float* out_scores, uint32_t* out_counts, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,8 @@ import numpy as np
 from . import _abi
 from ._abi import (METRIC_IP, METRIC_L2, ROTATOR_FHT_KAC, ROTATOR_MATRIX, RBQ_OK)
 
+ROTATOR_NONE = 2
+
 
 class Metric:
     L2 = METRIC_L2
@@ -27,6 +29,7 @@ class Metric:
 class RotatorType:
     MatrixRotator = ROTATOR_MATRIX
     FhtKacRotator = ROTATOR_FHT_KAC
+    NoRotation = ROTATOR_NONE  # MSTG posting lists (quantised in the raw space)
 
 
 _ERR_NAMES = {

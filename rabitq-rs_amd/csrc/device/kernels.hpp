@@ -108,6 +108,9 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
             for (uint32_t i = tid; i < D; i += kThreads) x[i] = x[i] * 0.25f;
             __syncthreads();
         }
+    } else if (rotator == 2) { // RBQ_ROTATOR_NONE: MSTG posting lists are quantised in the raw space
+        for (uint32_t i = tid; i < D; i += kThreads) x[i] = i < dim ? qin[i] : 0.0f;
+        __syncthreads();
     } else { // MatrixRotator::rotate_into: sequential unfused accumulate per output row
         for (uint32_t i = tid; i < D; i += kThreads) y[i] = i < dim ? qin[i] : 0.0f;
         __syncthreads();

@@ -386,4 +386,73 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     }
 }
 
+// MSTG posting-list scan: the caller supplies each query's posting lists; this emits the
+// per-list constants of search_posting_list_fastscan (g_add = l2_distance_sqr(query, centroid) or -dot in
+// canonical order, g_error = 0; src/mstg/index.rs:227-231) and the block work list, in the given order.
+// dynamic LDS: qrot[D] f32 | part[256] u32
+__global__ __launch_bounds__(kThreads) void k_probes_given(const uint32_t* __restrict__ list_ids,
+                                                           const uint32_t* __restrict__ list_counts, uint32_t max_lists,
+                                                           uint32_t nlist, int metric, const float* __restrict__ rot,
+                                                           const float* __restrict__ cent, uint32_t D,
+                                                           const uint32_t* __restrict__ list_gb0,
+                                                           const uint32_t* __restrict__ list_n,
+                                                           ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
+                                                           uint64_t wl_stride, uint32_t* __restrict__ nstream) {
+    extern __shared__ __align__(16) unsigned char smraw[];
+    float* qrot = reinterpret_cast<float*>(smraw);
+    uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, l2 = tid & 1u, grp = tid >> 1;
+    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
+    __syncthreads();
+    const uint32_t cnt = list_counts[q] < max_lists ? list_counts[q] : max_lists;
+    const uint32_t* mine = list_ids + (size_t)q * max_lists;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += kThreads / 2) {
+        const uint32_t r = i0 + grp;
+        if (r < cnt) {
+            const uint32_t cid = mine[r];
+            float s = 0.0f;
+            if (cid < nlist) {
+                const float* c = cent + (size_t)cid * D;
+                s = metric == 0 ? canon_pair2<0>(qrot, c, D, l2) : canon_pair2<1>(qrot, c, D, l2);
+            }
+            if (l2 == 0) {
+                ProbeInfo pi;
+                pi.g_add = metric == 0 ? s : -s;
+                pi.g_err = 0.0f;
+                pi.dotqc = 0.0f;
+                pi.cid = cid;
+                probe[(size_t)q * max_lists + r] = pi;
+            }
+        }
+    }
+    const uint32_t per = (cnt + kThreads - 1) / kThreads;
+    const uint32_t r0 = tid * per, r1 = (r0 + per < cnt) ? r0 + per : cnt;
+    uint32_t local = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t cid = mine[r];
+        if (cid < nlist) local += (list_n[cid] + 31u) >> 5;
+    }
+    part[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < kThreads; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
+        nstream[q] = run;
+    }
+    __syncthreads();
+    uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t cid = mine[r];
+        if (cid >= nlist) continue;
+        const uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
+            WorkItem wi;
+            wi.gblock = gb + b;
+            wi.rank_nvalid = (r << 6) | nv;
+            wl[pos++] = wi;
+        }
+    }
+}
+
 } // namespace rbq

@@ -179,13 +179,16 @@ int validate_header(const rbq_header* h) {
     if (h->dim == 0) return fail(RBQ_INVALID_CONFIG, "dimension must be positive");
     if (h->padded_dim < h->dim) return fail(RBQ_INVALID_CONFIG, "padded_dim must be >= dim");
     if (h->metric > 1) return fail(RBQ_INVALID_CONFIG, "unknown metric tag");
-    if (h->rotator > 1) return fail(RBQ_INVALID_CONFIG, "unknown rotator type tag");
+    if (h->rotator > RBQ_ROTATOR_NONE) return fail(RBQ_INVALID_CONFIG, "unknown rotator type tag");
     if (h->ex_bits != 0 && h->ex_bits != 2 && h->ex_bits != 6)
         return fail(RBQ_INVALID_CONFIG, "Unsupported ex_bits: only 0 (1-bit total), 2 (3-bit total), and 6 (7-bit total) are supported");
     if (h->padded_dim % 16 != 0) return fail(RBQ_INVALID_CONFIG, "Dimension must be multiple of 16 for SIMD");
     if (h->padded_dim > 2048)
         return fail(RBQ_INVALID_CONFIG, "padded_dim > 2048 (high-accuracy i32 LUT mode) is not supported");
-    if (h->rotator == RBQ_ROTATOR_FHT_KAC) {
+    if (h->rotator == RBQ_ROTATOR_NONE) {
+        if (h->padded_dim != h->dim) return fail(RBQ_INVALID_CONFIG, "rotator NONE requires padded_dim == dim");
+        if (h->rotator_len != 0) return fail(RBQ_INVALID_CONFIG, "rotator NONE takes no rotator blob");
+    } else if (h->rotator == RBQ_ROTATOR_FHT_KAC) {
         if (h->padded_dim % 64 != 0) return fail(RBQ_INVALID_CONFIG, "FHT rotator requires dimension to be multiple of 64");
         if (h->rotator_len != (uint64_t)4 * h->padded_dim / 8) return fail(RBQ_INVALID_PERSISTENCE, "FHT rotator flip bits length mismatch");
     } else {
@@ -286,7 +289,8 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
             }
         }
     }
-    std::vector<uint8_t> blob(hdr->rotator_blob, hdr->rotator_blob + hdr->rotator_len);
+    std::vector<uint8_t> blob;
+    if (hdr->rotator_len) blob.assign(hdr->rotator_blob, hdr->rotator_blob + hdr->rotator_len);
     std::vector<uint64_t> nblk(ix->n_lists);
     for (uint64_t c = 0; c < ix->n_lists; ++c) nblk[c] = (ln[c] + 31u) / 32u;
     std::sort(nblk.begin(), nblk.end(), std::greater<uint64_t>());
@@ -375,6 +379,34 @@ hipError_t launch_scan(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t
     }
 }
 
+// k_scan launch shared by the IVF search and the MSTG posting-list scan
+int scan_stage(rbq_index* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, uint32_t top_k, uint64_t wl_stride,
+               const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
+               rbq_diag* d_diag, bool mstg, hipStream_t stream) {
+    const uint32_t D = ix->D, Dc = ix->Dc;
+    ProfScope ps(ix, 3, stream);
+    ScanParams P;
+    P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
+    P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
+    P.bsum = (const BlockSummary*)ix->d_bsum;
+    P.lut = (const uint8_t*)w->lut.p; P.rot = (const float*)w->rot.p; P.consts = (const QueryConsts*)w->consts.p;
+    P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const WorkItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
+    P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
+    P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
+    P.D = D; P.Dc = Dc; P.nprobe = probe_stride; P.top_k = top_k; P.metric = ix->metric;
+    P.ex_bits = mstg ? 0u : ix->ex_bits; // MSTG search never evaluates the ex codes (src/mstg/index.rs:216-330)
+    P.no_block_bound = ix->no_block_bound ? 1u : 0u;
+    P.mstg = mstg ? 1u : 0u;
+    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, top_k);
+    hipError_t e;
+    if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
+    else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream);
+    else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream);
+    else e = launch_scan<0>(P, (uint32_t)nq, lds, stream);
+    HIP_TRY(e);
+    return RBQ_OK;
+}
+
 // Core: everything on device pointers, enqueued on `stream`. Workspace buffers come from `w`.
 int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t nq, uint32_t top_k, uint32_t nprobe_in,
                   const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
@@ -460,26 +492,8 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             HIP_TRY(hipGetLastError());
         }
     }
-    {
-        ProfScope ps(ix, 3, stream);
-        ScanParams P;
-        P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
-        P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
-        P.bsum = (const BlockSummary*)ix->d_bsum;
-        P.lut = (const uint8_t*)w->lut.p; P.rot = (const float*)w->rot.p; P.consts = (const QueryConsts*)w->consts.p;
-        P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const WorkItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
-        P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
-        P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
-        P.D = D; P.Dc = Dc; P.nprobe = nprobe; P.top_k = top_k; P.metric = ix->metric; P.ex_bits = ix->ex_bits;
-        P.no_block_bound = ix->no_block_bound ? 1u : 0u;
-        const size_t lds = scan_lds_bytes(Dc, D, ix->ex_bits, top_k);
-        hipError_t e;
-        if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
-        else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream);
-        else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream);
-        else e = launch_scan<0>(P, (uint32_t)nq, lds, stream);
-        HIP_TRY(e);
-    }
+    return scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
+                      /*mstg=*/false, stream);
     return RBQ_OK;
 }
 
@@ -726,6 +740,97 @@ int rbq_search_batch(const rbq_index* cix, const float* queries, uint64_t nq, ui
             HIP_TRY(hipMemcpyAsync(out_counts + q0, w->out_counts.p, n * 4, hipMemcpyDeviceToHost, w->stream));
             if (diag) HIP_TRY(hipMemcpyAsync(diag + q0, w->diag.p, n * sizeof(rbq_diag), hipMemcpyDeviceToHost, w->stream));
             HIP_TRY(hipStreamSynchronize(w->stream));
+        }
+        return RBQ_OK;
+    };
+    rc = run();
+    if (rc) (void)hipStreamSynchronize(w->stream);
+    give_ws(ix, w);
+    return rc;
+}
+
+
+// ---- MSTG posting-list scan ------------------------------------------------------------
+int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
+                           const uint32_t* list_ids, const uint32_t* list_counts, uint32_t max_lists,
+                           uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
+    g_err.clear();
+    rbq_index* ix = const_cast<rbq_index*>(cix);
+    int rc = check_query_args(ix, query_dim);
+    if (rc) return rc;
+    if (ix->rotator != RBQ_ROTATOR_NONE) return fail(RBQ_INVALID_CONFIG, "posting-list scan needs an index created with rotator NONE");
+    if (nq == 0) return RBQ_OK;
+    if (!queries || !list_ids || !list_counts || !out_ids || !out_scores || !out_counts) return fail(RBQ_INVALID_CONFIG, "null buffer");
+    if (top_k == 0) { std::memset(out_counts, 0, nq * 4); return RBQ_OK; }
+    if (top_k > 4096) return fail(RBQ_INVALID_CONFIG, "top_k > 4096 is not supported by the GPU top-k stage");
+    if (max_lists == 0) {
+        std::memset(out_counts, 0, nq * 4);
+        for (uint64_t i = 0; i < nq * top_k; ++i) { out_ids[i] = ~0ull; out_scores[i] = NAN; }
+        return RBQ_OK;
+    }
+    if (max_lists > (1u << 26)) return fail(RBQ_INVALID_CONFIG, "too many lists per query");
+    HIP_TRY(hipSetDevice(ix->device));
+    // exact work-list bound from the host copy of the list sizes (a list may legally repeat)
+    uint64_t wl_stride = 1;
+    for (uint64_t q = 0; q < nq; ++q) {
+        uint64_t tot = 0;
+        const uint32_t n = std::min(list_counts[q], max_lists);
+        for (uint32_t r = 0; r < n; ++r) {
+            const uint32_t cid = list_ids[q * max_lists + r];
+            if (cid < ix->n_lists) tot += (ix->h_list_n[cid] + 31u) / 32u;
+        }
+        wl_stride = std::max(wl_stride, tot);
+    }
+    if (wl_stride > 0xffffffffull) return fail(RBQ_INVALID_CONFIG, "posting lists too long for one query");
+    Workspace* w = take_ws(ix);
+    if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
+    auto run = [&]() -> int {
+        int r2;
+        const uint32_t D = ix->D, Dc = ix->Dc;
+        const uint64_t CH = 16384;
+        DevBuf& d_lists = w->scores; // reuse: [n][max_lists] u32
+        DevBuf& d_cnts = w->nvec;    // reuse: [n] u32
+        for (uint64_t q0 = 0; q0 < nq; q0 += CH) {
+            const uint64_t n = std::min(CH, nq - q0);
+            if ((r2 = w->queries.ensure(n * query_dim * 4))) return r2;
+            if ((r2 = w->rot.ensure(n * D * 4))) return r2;
+            if ((r2 = w->lut.ensure(n * (size_t)Dc * 4))) return r2;
+            if ((r2 = w->consts.ensure(n * sizeof(QueryConsts)))) return r2;
+            if ((r2 = d_lists.ensure(n * (size_t)max_lists * 4))) return r2;
+            if ((r2 = d_cnts.ensure(n * 8))) return r2;
+            if ((r2 = w->probe.ensure(n * (size_t)max_lists * sizeof(ProbeInfo)))) return r2;
+            if ((r2 = w->wl.ensure(n * wl_stride * sizeof(WorkItem)))) return r2;
+            if ((r2 = w->nstream.ensure(n * 4))) return r2;
+            if ((r2 = w->out_ids.ensure(n * top_k * 8))) return r2;
+            if ((r2 = w->out_scores.ensure(n * top_k * 4))) return r2;
+            if ((r2 = w->out_counts.ensure(n * 4))) return r2;
+            hipStream_t st = w->stream;
+            HIP_TRY(hipMemcpyAsync(w->queries.p, queries + q0 * query_dim, n * query_dim * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_lists.p, list_ids + q0 * max_lists, n * (size_t)max_lists * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d_cnts.p, list_counts + q0, n * 4, hipMemcpyHostToDevice, st));
+            {
+                ProfScope ps(ix, 0, st);
+                hipLaunchKernelGGL(k_prep, dim3((uint32_t)n), dim3(kThreads), (size_t)D * 4 * 2, st, (const float*)w->queries.p, ix->dim,
+                                   D, Dc, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, 0u,
+                                   (float*)w->rot.p, (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p);
+                HIP_TRY(hipGetLastError());
+            }
+            {
+                ProfScope ps(ix, 2, st);
+                hipLaunchKernelGGL(k_probes_given, dim3((uint32_t)n), dim3(kThreads), (size_t)D * 4 + kThreads * 4, st,
+                                   (const uint32_t*)d_lists.p, (const uint32_t*)d_cnts.p, max_lists, (uint32_t)ix->n_lists,
+                                   (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
+                                   (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
+                                   (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p);
+                HIP_TRY(hipGetLastError());
+            }
+            if ((r2 = scan_stage(ix, w, n, max_lists, top_k, wl_stride, nullptr, 0, (uint64_t*)w->out_ids.p,
+                                 (float*)w->out_scores.p, (uint32_t*)w->out_counts.p, nullptr, /*mstg=*/true, st)))
+                return r2;
+            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, w->out_ids.p, n * top_k * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, w->out_scores.p, n * top_k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_counts + q0, w->out_counts.p, n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
         return RBQ_OK;
     };

@@ -52,6 +52,8 @@ struct ScanParams {
     unsigned long long* diag; // [nq][3] or null
     uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
     uint32_t no_block_bound; // diagnostic: stream every probed block (measures the pure streaming rate)
+    uint32_t mstg;           // MSTG posting-list semantics (src/mstg/index.rs:216-330): distance = binary estimate,
+                             // non-finite dropped, L2 clamped to >= 0, no error-bound term
 };
 
 #ifndef RBQ_SCAN_WAVES
@@ -630,7 +632,13 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 STAMP(st_b); st_look += st_b - st_a;
 #endif
                 lb = lb_of(m_c, (float)accu, ip, est);
-                if (!finite_f(lb)) lb = P.metric == 0 ? 0.0f : -(m_c.dotqc + qc.qnorm);
+                if (P.mstg) {
+                    if (!finite_f(est)) valid = false;          // `if distance.is_finite()`
+                    if (P.metric == 0) est = fmaxf(est, 0.0f);  // distance.max(0.0)
+                    lb = est;                                   // f_error row and g_error are zero
+                } else if (!finite_f(lb)) {
+                    lb = P.metric == 0 ? 0.0f : -(m_c.dotqc + qc.qnorm);
+                }
                 surv = valid && (lb < T);
             }
             if (valid && !surv) ++n_skip;
@@ -764,7 +772,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         float sc = __int_as_float(0x7fc00000);
         if (i < len) {
             id = P.ids[heap_s[i]];
-            sc = P.metric == 0 ? heap_d[i] : -heap_d[i];
+            sc = (P.metric == 0 || P.mstg) ? heap_d[i] : -heap_d[i]; // MSTG reports the distance for both metrics
         }
         P.out_ids[(size_t)q * top_k + i] = id;
         P.out_scores[(size_t)q * top_k + i] = sc;

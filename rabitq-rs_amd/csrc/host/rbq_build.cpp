@@ -420,7 +420,10 @@ int rbq_build_train_with_clusters(const float* data, uint64_t n, uint32_t dim,
     rbq_built* b = new rbq_built();
     std::memset(&b->hdr, 0, sizeof b->hdr);
     b->hdr.dim = dim; b->hdr.padded_dim = D; b->hdr.metric = metric; b->hdr.rotator = rotator_type; b->hdr.ex_bits = (uint8_t)ex_bits;
-    if (rotator_type == RBQ_ROTATOR_FHT_KAC) {
+    if (rotator_type > RBQ_ROTATOR_NONE) { delete b; return RBQ_INVALID_CONFIG; }
+    if (rotator_type == RBQ_ROTATOR_NONE) {
+        if (dim % 16 != 0) { delete b; return RBQ_INVALID_CONFIG; } // FastScan asserts dim % 16 == 0
+    } else if (rotator_type == RBQ_ROTATOR_FHT_KAC) {
         Rng rng(seed);
         b->rotator_blob.resize(4 * D / 8);
         for (auto& x : b->rotator_blob) x = (uint8_t)(rng.next() >> 56);
@@ -431,6 +434,7 @@ int rbq_build_train_with_clusters(const float* data, uint64_t n, uint32_t dim,
     }
     auto rotate = [&](const float* in, float* o) {
         if (rotator_type == RBQ_ROTATOR_FHT_KAC) fht_kac_rotate(dim, D, b->rotator_blob.data(), in, o);
+        else if (rotator_type == RBQ_ROTATOR_NONE) std::memcpy(o, in, sizeof(float) * dim);
         else matrix_rotate(dim, D, (const float*)b->rotator_blob.data(), in, o);
     };
     bool has_t = use_faster_config && ex_bits > 0;
@@ -539,6 +543,7 @@ void rbq_build_pack_codes(const uint8_t* codes, uint64_t num_vectors, uint64_t d
 uint32_t rbq_build_crc32(const uint8_t* p, uint64_t n) { return crc32_update(0, p, n); }
 void rbq_build_rotate(const rbq_header* h, const float* in, float* out) {
     if (h->rotator == RBQ_ROTATOR_FHT_KAC) fht_kac_rotate(h->dim, h->padded_dim, h->rotator_blob, in, out);
+    else if (h->rotator == RBQ_ROTATOR_NONE) std::memcpy(out, in, sizeof(float) * h->dim);
     else matrix_rotate(h->dim, h->padded_dim, (const float*)h->rotator_blob, in, out);
 }
 

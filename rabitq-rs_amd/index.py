@@ -38,6 +38,8 @@ def lib():
         L.rbq_search_batch_device.restype = C.c_int
         L.rbq_search_batch_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                               C.c_uint64, vp, vp, vp, vp, vp]
+        L.rbq_posting_scan_batch.restype = C.c_int
+        L.rbq_posting_scan_batch.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, vp, vp]
         L.rbq_profile_begin.argtypes = [vp]
         L.rbq_profile_end.argtypes = [vp]
         L.rbq_profile_stage_ms.restype = C.c_double
@@ -181,6 +183,20 @@ class IvfRabitqIndex:
             c = int(counts[q])
             out.append(np.stack([ids[q, :c].astype(np.float32), scores[q, :c]], axis=1))
         return out
+
+    def posting_scan(self, queries, top_k, list_ids, list_counts):
+        """MSTG posting-list scan (reference src/mstg/index.rs:149-330): the caller has already chosen each
+        query's posting lists. Returns (ids[nq,k] u64, distances[nq,k] f32 ascending, counts[nq] u32)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        li = np.ascontiguousarray(list_ids, dtype=np.uint32)
+        lc = np.ascontiguousarray(list_counts, dtype=np.uint32)
+        nq, qd = q.shape
+        ids = np.empty((nq, top_k), np.uint64)
+        scores = np.empty((nq, top_k), np.float32)
+        counts = np.zeros(nq, np.uint32)
+        _check(lib().rbq_posting_scan_batch(self._h, q.ctypes.data, nq, qd, top_k, li.ctypes.data, lc.ctypes.data,
+                                            li.shape[1], ids.ctypes.data, scores.ctypes.data, counts.ctypes.data))
+        return ids, scores, counts
 
     # -- device-pointer entry (bench / torch interop) --------------------------------
     def search_batch_device(self, d_queries, nq, query_dim, top_k, nprobe, d_ids, d_scores, d_counts,

@@ -214,3 +214,56 @@ def test_large_batch_property_checks():
     assert np.array_equal(ids, oids)
     np.testing.assert_allclose(sc, osc, rtol=RTOL)
     idx.close()
+
+
+# ---- MSTG posting-list scan ------------------------------------------------------------------
+def _mstg_case(metric, bits, dim=128, n=6000, nlist=48, nq=40, seed=31):
+    rng = np.random.default_rng(seed)
+    data = make_dataset(n, dim, 12, seed, normalize=(metric == 1))
+    cent, assign = rq.builder.kmeans(data, nlist, 5, seed)
+    built = rq.builder.train_with_clusters(data, cent, assign, bits, metric, rq.RotatorType.NoRotation, seed, True)
+    q = make_dataset(nq, dim, 12, seed + 1, normalize=(metric == 1))
+    # stand-in for MstgIndex's HNSW centroid search + dynamic pruning: nearest centroids, ragged counts
+    d = ((q[:, None, :] - cent[None, :, :]) ** 2).sum(-1)
+    order = np.argsort(d, axis=1).astype(np.uint32)
+    max_lists = 12
+    counts = rng.integers(1, max_lists + 1, nq).astype(np.uint32)
+    counts[0] = 0  # a query with no selected list
+    lists = order[:, :max_lists].copy()
+    return built, q, lists, counts
+
+
+@pytest.mark.parametrize("metric,bits", [(0, 7), (1, 7), (0, 1), (0, 3)])
+def test_mstg_posting_scan_matches_oracle(metric, bits):
+    built, q, lists, counts = _mstg_case(metric, bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    for top_k in (10, 100):
+        rc, oids, osc, ocnt = oracle.posting_scan_batch(built, q, top_k, lists, counts)
+        assert rc == 0
+        ids, sc, cnt = idx.posting_scan(q, top_k, lists, counts)
+        assert np.array_equal(cnt, ocnt) and cnt[0] == 0
+        for i in range(len(q)):
+            c = int(cnt[i])
+            if c == 0:
+                continue
+            assert np.array_equal(sc[i, :c].view(np.uint32) & 0x7fffffff if metric == 0 else sc[i, :c].view(np.uint32),
+                                  osc[i, :c].view(np.uint32) & 0x7fffffff if metric == 0 else osc[i, :c].view(np.uint32))
+            assert (np.diff(sc[i, :c]) >= 0).all()
+            if metric == 0:
+                assert (sc[i, :c] >= 0).all()  # L2 estimates clamped at 0
+            # ids agree wherever the distance is unique (the reference leaves ties unordered)
+            uniq = np.ones(c, bool)
+            uniq[1:] &= sc[i, 1:c] != sc[i, :c - 1]
+            uniq[:-1] &= sc[i, :c - 1] != sc[i, 1:c]
+            assert np.array_equal(ids[i, :c][uniq], oids[i, :c][uniq])
+            assert sorted(ids[i, :c].tolist()) == sorted(oids[i, :c].tolist())
+    idx.close()
+
+
+def test_mstg_posting_scan_rejects_rotated_index():
+    data, built = build_index(n=500, dim=64, nlist=4, total_bits=7)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    with pytest.raises(rq.RabitqError) as e:
+        idx.posting_scan(data[:2], 5, np.zeros((2, 2), np.uint32), np.ones(2, np.uint32))
+    assert e.value.kind == "InvalidConfig"
+    idx.close()

@@ -272,3 +272,25 @@ def test_rbq1_header_and_crc_facts():
     body = np.frombuffer(blob[8:-4], np.uint8)
     import zlib
     assert int.from_bytes(blob[-4:], "little") == zlib.crc32(bytes(body)) == B().rbq_build_crc32(body.ctypes.data, len(body))
+
+
+def test_mstg_posting_scan_oracle_properties():
+    """search_posting_list_fastscan + top-k (reference src/mstg/index.rs:149-330): estimates of the selected
+    lists only, finite, L2-clamped, ascending; equal to the IVF estimator with f_error = g_error = 0."""
+    data = make_dataset(2000, 64, 6, 3)
+    cent, assign = builder.kmeans(data, 16, 4, 3)
+    built = builder.train_with_clusters(data, cent, assign, 1, 0, rq.RotatorType.NoRotation, 3, True)
+    q = make_dataset(8, 64, 6, 4)
+    lists = np.tile(np.array([[3, 7, 11]], np.uint32), (8, 1))
+    counts = np.full(8, 3, np.uint32)
+    rc, ids, sc, cnt = oracle.posting_scan_batch(built, q, 20, lists, counts)
+    assert rc == 0 and (cnt == 20).all()
+    allowed = set(np.concatenate([built.list_ids(c) for c in (3, 7, 11)]).tolist())
+    assert set(ids.ravel().tolist()) <= allowed
+    assert (np.diff(sc, axis=1) >= 0).all() and (sc >= 0).all() and np.isfinite(sc).all()
+    # with 1-bit codes, no rotation and every list selected the IVF path ranks by the same estimate
+    all_lists = np.tile(np.arange(16, dtype=np.uint32)[None, :], (8, 1))
+    rc, ids2, sc2, cnt2 = oracle.posting_scan_batch(built, q, 5, all_lists, np.full(8, 16, np.uint32))
+    rc, iids, isc, icnt, _ = oracle.search_batch(built, q, 5, 16)
+    pos = isc > 0  # the IVF path does not clamp
+    assert np.array_equal(np.sort(sc2[pos]), np.sort(isc[pos]))
