@@ -73,6 +73,7 @@ constexpr int kScanThreads = (kNScan + 1) * 64; // scanner waves + 1 replay wave
 constexpr int kTileBlocks = 2 * kNScan;         // 32-vector blocks per tile (one per scanner half-wave)
 constexpr int kTileCand = kTileBlocks * 32;     // candidates per tile
 constexpr uint32_t kLightMax = RBQ_LIGHT_MAX;   // tiles with more survivors than this run synchronously
+constexpr uint32_t kBatchDone = 0xffffffffu;
 
 // Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 units of 16 B, stored [unit][lane][16 B].
 // Lane l holds the codes of dims 16t+l (t = 0..D/16-1); unit j packs codes t = j*CPU .. j*CPU+CPU-1 as a
@@ -371,13 +372,13 @@ struct RegHeap {
 // LDS carve-up (dynamic only, LUT at byte 0):
 //   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
 //   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
-//   T, len, nskip, pad
+//   T, len, nskip, nbatch | batch[kScanThreads/16] u32
 constexpr int kWindow = kNScan * 64;               // blocks examined per fill step: one per scanner lane
 constexpr int kQueueCap = 256;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 __host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
     return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * 8 + 16;
+           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * 8 + 16 + (kScanThreads / 16) * 4;
 }
 
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
@@ -404,6 +405,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     float& s_T = *reinterpret_cast<float*>(s_misc);
     uint32_t& s_len = *(s_misc + 1);
     uint32_t* s_nskip = s_misc + 2;
+    uint32_t& s_nbatch = *(s_misc + 3);   // refine batch size of the current round (kBatchDone = tile finished)
+    uint32_t* s_batch = s_misc + 4;       // [kScanThreads/16] queue positions to refine in this round
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u, half = lane >> 5, l32 = lane & 31u;
@@ -445,42 +448,22 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             q_d[e] = a + m;
         }
     };
-    auto refine = [&](uint32_t buf, uint32_t S, uint32_t g0, uint32_t gstep) {
+    // group `g` (16 lanes) refines the survivor at queue position s_batch[g] of tile buffer `buf`
+    auto refine_batch = [&](uint32_t buf, uint32_t nb, uint32_t g) {
         const uint32_t gl = tid & 15u;
-        if (nunits <= (uint32_t)kExRegUnits) {
-            // software-pipelined over survivors: the next survivor's units are loading while this one is summed
-            uint4 cur[kExRegUnits], nxt[kExRegUnits];
-            uint32_t i = g0, e = 0, sl = 0;
-            if (i < S) {
-                e = buf * kTileCand + s_list[i];
-                sl = q_slot[e];
-                ex_load_all(cur, P.ex_codes + (size_t)sl * exb, gl, nunits);
+        if (g < nb) {
+            const uint32_t e = buf * kTileCand + s_batch[g];
+            const uint32_t sl = q_slot[e];
+            const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
+            float sacc;
+            if (nunits <= (uint32_t)kExRegUnits) {
+                uint4 u[kExRegUnits];
+                ex_load_all(u, ex, gl, nunits);
+                sacc = ex_bits == 6 ? ex_dot_all<6>(u, s_q, gl, nunits) : ex_dot_all<2>(u, s_q, gl, nunits);
+            } else {
+                sacc = ex_bits == 6 ? ex_dot_units<6>(ex, s_q, gl, nunits) : ex_dot_units<2>(ex, s_q, gl, nunits);
             }
-            while (i < S) {
-                const uint32_t ni = i + gstep;
-                uint32_t ne = 0, nsl = 0;
-                if (ni < S) {
-                    ne = buf * kTileCand + s_list[ni];
-                    nsl = q_slot[ne];
-                    ex_load_all(nxt, P.ex_codes + (size_t)nsl * exb, gl, nunits);
-                }
-                uint32_t opaque = 0; // keeps the (survivor-invariant) query reads inside the loop: hoisting
-                asm volatile("" : "+v"(opaque)); // them would cost D/16 registers for the whole kernel
-                const float* sq = s_q + opaque;
-                const float sacc = ex_bits == 6 ? ex_dot_all<6>(cur, sq, gl, nunits) : ex_dot_all<2>(cur, sq, gl, nunits);
-                refine_finish(e, sl, sacc);
-#pragma unroll
-                for (int j = 0; j < kExRegUnits; ++j) cur[j] = nxt[j];
-                i = ni; e = ne; sl = nsl;
-            }
-        } else {
-            for (uint32_t i = g0; i < S; i += gstep) {
-                const uint32_t e = buf * kTileCand + s_list[i];
-                const uint32_t sl = q_slot[e];
-                const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
-                const float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, s_q, gl, nunits) : ex_dot_units<2>(ex, s_q, gl, nunits);
-                refine_finish(e, sl, sacc);
-            }
+            refine_finish(e, sl, sacc);
         }
     };
 
@@ -529,7 +512,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
     uint32_t st_nheavy = 0, st_surv = 0, st_ntile = 0, st_dead = 0;
-    unsigned long long st_hB = 0, st_hR = 0, st_hD = 0;
+    uint32_t st_rounds = 0;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
 #else
 #define STAMP(x)
@@ -664,20 +647,20 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
             st_surv += S;
 #endif
-            if (S > kLightMax) { // synchronous tile: help refining, then wait for the fresh threshold
+            if (S > kLightMax) { // synchronous tile: help refining round by round, then use the fresh threshold
                 STAMP(st_a);
-                lds_barrier();   // B: survivor list compacted
+                while (true) {
+                    lds_barrier(); // B_r: this round's refine batch (or the end marker) is published
+                    const uint32_t nb = s_nbatch;
+                    if (nb == kBatchDone) break;
 #ifdef RBQ_STAMPS
-                STAMP(st_b); st_hB += st_b - st_a;
+                    ++st_rounds;
 #endif
-                if (ex_bits) refine(buf, S, tid >> 4, kScanThreads / 16);
+                    refine_batch(buf, nb, tid >> 4);
+                    lds_barrier(); // C_r: refined distances visible to the replay wave
+                }
 #ifdef RBQ_STAMPS
-                STAMP(st_c); st_hR += st_c - st_b;
-#endif
-                lds_barrier();   // C: refined distances visible
-                lds_barrier();   // D: replay done, s_T updated
-#ifdef RBQ_STAMPS
-                STAMP(st_b); st_hD += st_b - st_c; st_heavy += st_b - st_a; ++st_nheavy;
+                STAMP(st_b); st_heavy += st_b - st_a; ++st_nheavy;
 #endif
             }
         } else {
@@ -695,56 +678,83 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             for (int j = 0; j < kTileBlocks; ++j) S += __popc(s_mask[buf * kTileBlocks + j]);
             S = __builtin_amdgcn_readfirstlane(S);
             const bool heavy = S > kLightMax;
-            if (heavy) {
-                lds_barrier(); // B
-                if (ex_bits) refine(buf, S, tid >> 4, kScanThreads / 16);
-                lds_barrier(); // C
-            } else if (S) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (ex_bits) refine(buf, S, lane >> 4, 4);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            // exact sequential replay of the reference's prune/push/pop loop, in stream order
-            if (reg_heap) {
-                for (uint32_t c0 = 0; c0 < S; c0 += 64) {
-                    const uint32_t cnt = S - c0 < 64 ? S - c0 : 64;
-                    int v_lb = 0, v_d = 0;
-                    uint32_t v_s = 0;
-                    if (lane < cnt) { // lane i stages survivor c0+i
-                        const uint32_t e = buf * kTileCand + s_list[c0 + lane];
-                        v_lb = __float_as_int(q_lb[e]);
-                        v_d = __float_as_int(q_d[e]);
-                        v_s = q_slot[e];
+            // Exact sequential replay of the reference's prune/push/pop loop in stream order, with LAZY refine:
+            // a round takes the next survivors whose lb is below the CURRENT true threshold (a superset of the
+            // ones the reference evaluates, since the threshold only shrinks), refines them in parallel — 16
+            // groups with the scanners' help in a heavy tile, the wave's own 4 groups otherwise — and then
+            // replays the examined stretch against the running threshold.
+            const uint32_t G = ex_bits ? (heavy ? (uint32_t)(kScanThreads / 16) : 4u) : 64u;
+            uint32_t p = 0;
+            while (p < S) {
+                const float distk0 = reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
+                                              : (lh.len < top_k ? INFINITY : heap_d[0]);
+                const uint32_t i = p + lane;
+                uint32_t e = 0;
+                float lbv = INFINITY;
+                if (i < S) { e = buf * kTileCand + s_list[i]; lbv = q_lb[e]; }
+                const bool want = i < S && lbv < distk0;
+                const unsigned long long m = __ballot(want);
+                const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                const bool take = want && rank < G;
+                const unsigned long long mt = __ballot(take);
+                const uint32_t ncol = __popcll(mt);
+                uint32_t np = p + 64u < S ? p + 64u : S;
+                if ((uint32_t)__popcll(m) > G) np = p + (63u - (uint32_t)__builtin_clzll(mt)) + 1u; // stop after the G-th taken
+                if (ex_bits && ncol) {
+                    if (take) s_batch[rank] = s_list[i];
+                    if (heavy) {
+                        if (lane == 0) s_nbatch = ncol;
+                        lds_barrier(); // B_r
+                        refine_batch(buf, ncol, tid >> 4);
+                        lds_barrier(); // C_r
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        refine_batch(buf, ncol, lane >> 4);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)i));
+                }
+                // replay [p, np): lane j stages survivor p+j
+                const uint32_t cnt = np - p;
+                int v_lb = __float_as_int(lbv), v_d = 0;
+                uint32_t v_s = 0;
+                if (lane < cnt) { v_d = __float_as_int(q_d[e]); v_s = q_slot[e]; }
+                if (reg_heap) {
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)j));
                         const float distk = rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0));
                         if (lb >= distk) { ++n_skip; continue; }
                         ++n_ext;
-                        const int dbits = __builtin_amdgcn_readlane(v_d, (int)i);
+                        const int dbits = __builtin_amdgcn_readlane(v_d, (int)j);
                         if (!finite_f(__int_as_float(dbits))) continue;
                         ++n_est;
-                        rh.push(dbits, (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)i));
+                        rh.push(dbits, (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j));
                         if (rh.len > top_k) rh.pop();
                     }
+                } else {
+                    for (uint32_t j = 0; j < cnt; ++j) { // uniform values, heap in LDS (top_k >= 64)
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)j));
+                        const float distk = lh.len < top_k ? INFINITY : heap_d[0];
+                        if (lb >= distk) { ++n_skip; continue; }
+                        ++n_ext;
+                        const float d = __int_as_float(__builtin_amdgcn_readlane(v_d, (int)j));
+                        if (!finite_f(d)) continue;
+                        ++n_est;
+                        if (lane == 0) {
+                            lh.push(d, (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j));
+                            if (lh.len > top_k) lh.pop();
+                        }
+                        lh.len = (uint32_t)__builtin_amdgcn_readfirstlane((int)lh.len);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                 }
-                if (lane == 0) s_T = rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0));
-            } else if (lane == 0) {
-                for (uint32_t i = 0; i < S; ++i) {
-                    const uint32_t e = buf * kTileCand + s_list[i];
-                    const float lb = q_lb[e];
-                    const float distk = lh.len < top_k ? INFINITY : heap_d[0];
-                    if (lb >= distk) { ++n_skip; continue; }
-                    ++n_ext;
-                    const float d = q_d[e];
-                    if (!finite_f(d)) continue;
-                    ++n_est;
-                    lh.push(d, q_slot[e]);
-                    if (lh.len > top_k) lh.pop();
-                }
-                s_T = lh.len < top_k ? INFINITY : heap_d[0];
+                p = np;
             }
-            if (heavy) lds_barrier(); // D
+            if (lane == 0) s_T = reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
+                                          : (lh.len < top_k ? INFINITY : heap_d[0]);
+            if (heavy) {
+                if (lane == 0) s_nbatch = kBatchDone;
+                lds_barrier(); // final B: helpers leave the tile, fresh T is visible
+            }
         }
         qhead = (qhead + n) % kQueueCap;
         qcount -= n;
@@ -780,7 +790,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
     if (tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
         st_total = __builtin_amdgcn_s_memtime() - st_total;
-        P.diag[(size_t)q * 3 + 0] = (st_hB & 0xfffffull) | ((st_hR & 0xfffffull) << 20) | ((st_hD & 0xffffffull) << 40);
+        P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | ((unsigned long long)st_rounds << 32);
         P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | ((unsigned long long)st_nheavy << 32);
         P.diag[(size_t)q * 3 + 2] = (unsigned long long)st_surv | (st_fill << 32);
     }

@@ -15,8 +15,8 @@ q = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).cpu().nu
 for _ in range(2):
     ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
 d = diag.astype(np.uint64)
-hB = (d[:, 0] & 0xfffff).astype(np.float64); hR = ((d[:, 0] >> 20) & 0xfffff).astype(np.float64); hD = (d[:, 0] >> 40).astype(np.float64); heavy = hB + hR + hD; waitA = np.zeros(len(d)); ntile = dead = np.zeros(len(d))
-print('heavy split: wait-B %.0f  refine %.0f  C..D (replay) %.0f' % (hB.mean(), hR.mean(), hD.mean()))
+heavy = (d[:, 0] & 0xffffffff).astype(np.float64); rounds = (d[:, 0] >> 32).astype(np.float64); waitA = np.zeros(len(d)); ntile = dead = np.zeros(len(d))
+print('heavy refine rounds/query %.1f' % rounds.mean())
 total = (d[:, 1] & 0xffffffff).astype(np.float64); nheavy = (d[:, 1] >> 32).astype(np.float64)
 surv = (d[:, 2] & 0xffffffff).astype(np.float64); look = (d[:, 2] >> 32).astype(np.float64)
 print("per-query means (cycles of s_memtime): total %.0f  fill %.0f (%.0f%%)  waitA %.0f (%.0f%%)  heavy %.0f (%.0f%%)" % (
