@@ -518,6 +518,10 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #define STAMP(x)
 #endif
 
+#ifdef RBQ_STAMPS
+    const unsigned long long st_loop0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_tiles = 0, st_t0 = 0;
+#endif
     while (true) {
         if (pos < ns && qcount < (uint32_t)kTileBlocks) {
             // ---------------------------------------------------------------- fill step: examine kWindow blocks
@@ -582,6 +586,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         }
         if (qcount == 0) break;
         // -------------------------------------------------------------------- tile step
+        STAMP(st_t0);
         const uint32_t n = qcount < (uint32_t)kTileBlocks ? qcount : (uint32_t)kTileBlocks;
         const uint32_t buf = tile & 1u;
         if (scanner) {
@@ -680,47 +685,48 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             const bool heavy = S > kLightMax;
             // Exact sequential replay of the reference's prune/push/pop loop in stream order, with LAZY refine:
             // a round takes the next survivors whose lb is below the CURRENT true threshold (a superset of the
-            // ones the reference evaluates, since the threshold only shrinks), refines them in parallel — 16
-            // groups with the scanners' help in a heavy tile, the wave's own 4 groups otherwise — and then
+            // ones the reference evaluates, since the threshold only shrinks), refines them in parallel and then
             // replays the examined stretch against the running threshold.
-            const uint32_t G = ex_bits ? (heavy ? (uint32_t)(kScanThreads / 16) : 4u) : 64u;
-            uint32_t p = 0;
-            while (p < S) {
-                const float distk0 = reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
-                                              : (lh.len < top_k ? INFINITY : heap_d[0]);
-                const uint32_t i = p + lane;
-                uint32_t e = 0;
-                float lbv = INFINITY;
-                if (i < S) { e = buf * kTileCand + s_list[i]; lbv = q_lb[e]; }
-                const bool want = i < S && lbv < distk0;
-                const unsigned long long m = __ballot(want);
-                const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-                const bool take = want && rank < G;
-                const unsigned long long mt = __ballot(take);
-                const uint32_t ncol = __popcll(mt);
-                uint32_t np = p + 64u < S ? p + 64u : S;
-                if ((uint32_t)__popcll(m) > G) np = p + (63u - (uint32_t)__builtin_clzll(mt)) + 1u; // stop after the G-th taken
-                if (ex_bits && ncol) {
-                    if (take) s_batch[rank] = s_list[i];
-                    if (heavy) {
-                        if (lane == 0) s_nbatch = ncol;
-                        lds_barrier(); // B_r
-                        refine_batch(buf, ncol, tid >> 4);
-                        lds_barrier(); // C_r
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        refine_batch(buf, ncol, lane >> 4);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
+            struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
+            auto cur_distk = [&]() -> float {
+                return reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
+                                : (lh.len < top_k ? INFINITY : heap_d[0]);
+            };
+            // next batch from position p: stretches without a wanted survivor are skipped (and counted) on the way;
+            // the (at most G) wanted ones of the first stretch that has any go to s_batch
+            auto collect = [&](uint32_t p, uint32_t G, float distk0) -> Batch {
+                Batch bt;
+                while (true) {
+                    const uint32_t i = p + lane;
+                    uint32_t e = 0;
+                    float lbv = INFINITY;
+                    if (i < S) { e = buf * kTileCand + s_list[i]; lbv = q_lb[e]; }
+                    const bool want = i < S && lbv < distk0;
+                    const unsigned long long m = __ballot(want);
+                    uint32_t np = p + 64u < S ? p + 64u : S;
+                    if (m == 0ull && np < S) { n_skip += np - p; p = np; continue; }
+                    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+                    const bool take = want && rank < G;
+                    const unsigned long long mt = __ballot(take);
+                    if ((uint32_t)__popcll(m) > G) np = p + (63u - (uint32_t)__builtin_clzll(mt)) + 1u; // stop after the G-th taken
+                    if (ex_bits && take) s_batch[rank] = s_list[i];
+                    bt.p = p; bt.np = np; bt.ncol = (uint32_t)__popcll(mt); bt.e = e; bt.mt = mt; bt.v_lb = __float_as_int(lbv);
+                    return bt;
                 }
-                // replay [p, np): lane j stages survivor p+j
-                const uint32_t cnt = np - p;
-                int v_lb = __float_as_int(lbv), v_d = 0;
+            };
+            // replay [bt.p, bt.np): only the taken survivors can pass the running threshold (it never grows, so
+            // lb >= distk0 stays pruned); the rest of the stretch is counted as skipped in one step
+            auto replay = [&](const Batch& bt) {
+                int v_d = 0;
                 uint32_t v_s = 0;
-                if (lane < cnt) { v_d = __float_as_int(q_d[e]); v_s = q_slot[e]; }
+                if ((bt.mt >> lane) & 1ull) { v_d = __float_as_int(q_d[bt.e]); v_s = q_slot[bt.e]; }
+                unsigned long long todo = bt.mt;
+                n_skip += (bt.np - bt.p) - bt.ncol;
                 if (reg_heap) {
-                    for (uint32_t j = 0; j < cnt; ++j) {
-                        const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)j));
+                    while (todo) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(bt.v_lb, (int)j));
                         const float distk = rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0));
                         if (lb >= distk) { ++n_skip; continue; }
                         ++n_ext;
@@ -731,8 +737,10 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                         if (rh.len > top_k) rh.pop();
                     }
                 } else {
-                    for (uint32_t j = 0; j < cnt; ++j) { // uniform values, heap in LDS (top_k >= 64)
-                        const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)j));
+                    while (todo) { // uniform values, heap in LDS (top_k >= 64)
+                        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(bt.v_lb, (int)j));
                         const float distk = lh.len < top_k ? INFINITY : heap_d[0];
                         if (lb >= distk) { ++n_skip; continue; }
                         ++n_ext;
@@ -747,7 +755,39 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                 }
-                p = np;
+            };
+            if (!(heavy && ex_bits)) {
+                // light tile (or no ex codes): the wave refines with its own 4 groups while the scanners go on
+                const uint32_t G = ex_bits ? 4u : 64u;
+                uint32_t p = 0;
+                while (p < S) {
+                    const Batch bt = collect(p, G, cur_distk());
+                    if (ex_bits && bt.ncol) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        refine_batch(buf, bt.ncol, lane >> 4);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    replay(bt);
+                    p = bt.np;
+                }
+            } else {
+                // heavy tile, software-pipelined: round 0 is refined by all 16 groups; from then on the scanners'
+                // 12 groups refine batch r+1 — collected with the threshold as it stands BEFORE batch r is
+                // replayed, i.e. a superset again — while this wave replays batch r.
+                Batch cur = collect(0, (uint32_t)(kScanThreads / 16), cur_distk());
+                if (lane == 0) s_nbatch = cur.ncol;
+                lds_barrier(); // B_0
+                refine_batch(buf, cur.ncol, tid >> 4);
+                lds_barrier(); // C_0
+                while (cur.np < S) {
+                    const Batch nxt = collect(cur.np, (uint32_t)(kNScan * 4), cur_distk());
+                    if (lane == 0) s_nbatch = nxt.ncol;
+                    lds_barrier(); // B_r: the scanners start on batch r+1
+                    replay(cur);
+                    lds_barrier(); // C_r
+                    cur = nxt;
+                }
+                replay(cur);
             }
             if (lane == 0) s_T = reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
                                           : (lh.len < top_k ? INFINITY : heap_d[0]);
@@ -756,6 +796,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 lds_barrier(); // final B: helpers leave the tile, fresh T is visible
             }
         }
+#ifdef RBQ_STAMPS
+        STAMP(st_b); st_tiles += st_b - st_t0;
+#endif
         qhead = (qhead + n) % kQueueCap;
         qcount -= n;
         ++tile;
@@ -789,10 +832,11 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     }
 #ifdef RBQ_STAMPS
     if (tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
+        const unsigned long long st_total0 = st_total;
         st_total = __builtin_amdgcn_s_memtime() - st_total;
         P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | ((unsigned long long)st_rounds << 32);
-        P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | ((unsigned long long)st_nheavy << 32);
-        P.diag[(size_t)q * 3 + 2] = (unsigned long long)st_surv | (st_fill << 32);
+        P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | (((st_loop0 - st_total0) & 0xffffull) << 32) | ((unsigned long long)(tile & 0xffff) << 48);
+        P.diag[(size_t)q * 3 + 2] = (unsigned long long)(st_tiles & 0xffffffffull) | (st_fill << 32);
     }
     if (wave == (uint32_t)kNScan && lane == 0) { P.out_counts[q] = len; }
     if (false) {

@@ -17,8 +17,9 @@ for _ in range(2):
 d = diag.astype(np.uint64)
 heavy = (d[:, 0] & 0xffffffff).astype(np.float64); rounds = (d[:, 0] >> 32).astype(np.float64); waitA = np.zeros(len(d)); ntile = dead = np.zeros(len(d))
 print('heavy refine rounds/query %.1f' % rounds.mean())
-total = (d[:, 1] & 0xffffffff).astype(np.float64); nheavy = (d[:, 1] >> 32).astype(np.float64)
-surv = (d[:, 2] & 0xffffffff).astype(np.float64); look = (d[:, 2] >> 32).astype(np.float64)
+total = (d[:, 1] & 0xffffffff).astype(np.float64); prolog = ((d[:, 1] >> 32) & 0xffff).astype(np.float64); ntiles = (d[:, 1] >> 48).astype(np.float64); nheavy = np.zeros(len(d))
+tiles_t = (d[:, 2] & 0xffffffff).astype(np.float64); surv = np.zeros(len(d)); look = (d[:, 2] >> 32).astype(np.float64)
+print('prologue %.0f  tile steps total %.0f (incl. heavy)  tiles %.1f  -> per non-heavy tile %.0f' % (prolog.mean(), tiles_t.mean(), ntiles.mean(), (tiles_t.mean() - heavy.mean()) / max(ntiles.mean(), 1)))
 print("per-query means (cycles of s_memtime): total %.0f  fill %.0f (%.0f%%)  waitA %.0f (%.0f%%)  heavy %.0f (%.0f%%)" % (
     total.mean(), look.mean(), 100 * look.mean() / total.mean(), waitA.mean(), 100 * waitA.mean() / total.mean(), heavy.mean(), 100 * heavy.mean() / total.mean()))
 print("tiles/query %.1f dead(wave0) %.1f" % (ntile.mean(), dead.mean()))
