@@ -248,6 +248,7 @@ def main():
         "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
         "index_build_s": round(t_build, 1),
         "rank_fallbacks": int(idx.rank_fallbacks()),
+        "heap_restarts": int(idx.heap_restarts()),
         "roofline": {"bound": "hbm", "kernel": "k_scan", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": scan_ms,

@@ -166,10 +166,15 @@ uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
 /* Number of queries (since creation) whose probe selection fell back from the MFMA shortlist to the
  * all-lists canonical ranking (shortlist overflow / non-finite scores). Diagnostic. */
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
+/* Number of queries (since creation) that met two bit-identical distances in their top-k and were therefore
+ * re-run inside the scan kernel with the exact BinaryHeap emulation (src/ivf.rs:2078-2105 pushes into a
+ * std BinaryHeap, whose tie behaviour depends on its layout). Diagnostic. */
+uint64_t rbq_debug_heap_restarts(const rbq_index* idx);
 /* Diagnostic switches; results are identical under every setting, only the work done changes:
  *   "block_bound" 0      stream every probed block (no block-level lower-bound skipping)
  *   "exact_rank" 1       rank all nq x nlist pairs in canonical order instead of the MFMA shortlist
- *   "force_rank_fallback" 1   send every query through the shortlist's all-lists fallback */
+ *   "force_rank_fallback" 1   send every query through the shortlist's all-lists fallback
+ *   "exact_heap" 1       keep the top-k in the BinaryHeap emulation from the first candidate (no sorted fast path) */
 int rbq_debug_set_option(rbq_index* idx, const char* name, int value);
 
 const char* rbq_strerror(int code);

@@ -88,6 +88,7 @@ struct rbq_index {
          *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr;
     float cnorm2_max = 0.0f;
     bool no_block_bound = false; // rbq_debug_set_option("block_bound", 0)
+    bool exact_heap = false;     // rbq_debug_set_option("exact_heap", 1): BinaryHeap emulation from the first candidate
     bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
     bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
     // host
@@ -317,7 +318,7 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
         }
         ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
         UP(d_cnorm2, cn);
-        std::vector<unsigned int> z(1, 0);
+        std::vector<unsigned int> z(2, 0); // [0] rank fallbacks, [1] heap restarts
         UP(d_fallbacks, z);
         const char* e = std::getenv("RBQ_EXACT_RANK");
         ix->exact_rank = e && e[0] == '1';
@@ -396,6 +397,8 @@ int scan_stage(rbq_index* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, 
     P.D = D; P.Dc = Dc; P.nprobe = probe_stride; P.top_k = top_k; P.metric = ix->metric;
     P.ex_bits = mstg ? 0u : ix->ex_bits; // MSTG search never evaluates the ex codes (src/mstg/index.rs:216-330)
     P.no_block_bound = ix->no_block_bound ? 1u : 0u;
+    P.exact_heap = ix->exact_heap ? 1u : 0u;
+    P.heap_restarts = (unsigned int*)ix->d_fallbacks + 1;
     P.mstg = mstg ? 1u : 0u;
     const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, top_k);
     hipError_t e;
@@ -885,6 +888,7 @@ int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
     if (!ix || !name) return RBQ_INVALID_CONFIG;
     if (!std::strcmp(name, "block_bound")) { ix->no_block_bound = value == 0; return RBQ_OK; }
     if (!std::strcmp(name, "exact_rank")) { ix->exact_rank = value != 0; return RBQ_OK; }
+    if (!std::strcmp(name, "exact_heap")) { ix->exact_heap = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "force_rank_fallback")) { ix->force_rank_fallback = value != 0; return RBQ_OK; }
     return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
 }
@@ -894,6 +898,15 @@ uint64_t rbq_debug_rank_fallbacks(const rbq_index* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(&v, ix->d_fallbacks, 4, hipMemcpyDeviceToHost);
+    return v;
+}
+
+uint64_t rbq_debug_heap_restarts(const rbq_index* ix) {
+    if (!ix) return 0;
+    unsigned int v = 0;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(&v, (const unsigned int*)ix->d_fallbacks + 1, 4, hipMemcpyDeviceToHost);
     return v;
 }
 

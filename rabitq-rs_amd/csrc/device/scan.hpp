@@ -52,6 +52,8 @@ struct ScanParams {
     unsigned long long* diag; // [nq][3] or null
     uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
     uint32_t no_block_bound; // diagnostic: stream every probed block (measures the pure streaming rate)
+    uint32_t exact_heap;     // diagnostic: emulate the reference's BinaryHeap from the start (no sorted fast path)
+    unsigned int* heap_restarts; // counter of queries re-run with the exact heap after a distance tie (or null)
     uint32_t mstg;           // MSTG posting-list semantics (src/mstg/index.rs:216-330): distance = binary estimate,
                              // non-finite dropped, L2 clamped to >= 0, no error-bound term
 };
@@ -369,6 +371,31 @@ struct RegHeap {
     }
 };
 
+// ---- tie-free fast path of the same top-k --------------------------------------------------------------------
+// As long as no two distances in the heap are bit-identical, the reference's result does not depend on the
+// layout of its BinaryHeap: pop evicts THE maximum and into_sorted_vec has one possible order.  The replay wave
+// then keeps the top-k as a sorted run (entry i in lane i, ascending) with one ballot + one DPP shift per
+// insertion instead of a sift-up and a sift-down through v_readlane chains.  An insertion that meets an equal
+// key reports a tie; the query is then re-run from its first block with RegHeap (exact layout emulation).
+struct SortedTop { // operates on the registers of a RegHeap (only one of the two views is live at a time)
+    static __device__ __forceinline__ bool insert(RegHeap& h, int dbits, uint32_t slot, uint32_t top_k) {
+        const uint32_t lane = __lane_id();
+        const int ke = RegHeap::key(dbits), k = RegHeap::key(h.hd);
+        const bool in = lane < h.len;
+        const bool tie = __ballot(in && k == ke) != 0ull;
+        const uint32_t pos = (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
+        const int sd = __builtin_amdgcn_update_dpp(0, h.hd, 0x138, 0xf, 0xf, false);      // wave_shr:1
+        const int ss = __builtin_amdgcn_update_dpp(0, (int)h.hs, 0x138, 0xf, 0xf, false);
+        if (lane == pos) { h.hd = dbits; h.hs = slot; }
+        else if (lane > pos) { h.hd = sd; h.hs = (uint32_t)ss; }
+        h.len = h.len < top_k ? h.len + 1u : h.len; // a full run drops its (new) entry top_k
+        return tie;
+    }
+    static __device__ __forceinline__ float distk(const RegHeap& h, uint32_t top_k) {
+        return h.len < top_k ? INFINITY : __int_as_float(__builtin_amdgcn_readlane(h.hd, (int)RegHeap::uni(top_k - 1u)));
+    }
+};
+
 // LDS carve-up (dynamic only, LUT at byte 0):
 //   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
 //   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
@@ -378,7 +405,7 @@ constexpr int kQueueCap = 256;                    // live-block FIFO (>= kTileBl
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 __host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
     return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * 8 + 16 + (kScanThreads / 16) * 4;
+           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * 8 + 32 + (kScanThreads / 16) * 4;
 }
 
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
@@ -406,7 +433,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t& s_len = *(s_misc + 1);
     uint32_t* s_nskip = s_misc + 2;
     uint32_t& s_nbatch = *(s_misc + 3);   // refine batch size of the current round (kBatchDone = tile finished)
-    uint32_t* s_batch = s_misc + 4;       // [kScanThreads/16] queue positions to refine in this round
+    uint32_t& s_restart = *(s_misc + 4);  // a distance tie was met on the sorted fast path: re-run with the exact heap
+    uint32_t* s_batch = s_misc + 8;       // [kScanThreads/16] queue positions to refine in this round
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u, half = lane >> 5, l32 = lane & 31u;
@@ -425,7 +453,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         uint4* dst = reinterpret_cast<uint4*>(s_lut);
         for (uint32_t i = tid; i < Dc / 4; i += kScanThreads) dst[i] = src[i];
         for (uint32_t i = tid; i < qlen; i += kScanThreads) s_q[i] = i < D ? P.rot[(size_t)q * D + i] : 0.0f;
-        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; }
+        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; }
     }
     const QueryConsts qc = P.consts[q];
     const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
@@ -505,8 +533,13 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t pos = 0;                 // next unexamined stream block
     uint32_t qhead = 0, qcount = 0;   // live-block FIFO
     uint32_t tile = 0;                // tiles published so far (buffer = tile & 1)
+    // Blocks examined by the next fill step.  The first steps are small: with the threshold still at +inf the
+    // block bound passes everything, and whatever is queued then is paid for at tile time (factor rows, a
+    // barrier, usually no survivor).  Once the nearest lists have set a threshold the windows grow.
+    uint32_t win = (uint32_t)kTileBlocks;
     // replay-wave state
     const bool reg_heap = top_k < 64;
+    bool fast = reg_heap && !P.exact_heap && !P.mstg; // sorted-run top-k until a distance tie shows up
     RegHeap rh{0, 0u, 0u};
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
@@ -514,14 +547,18 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t st_nheavy = 0, st_surv = 0, st_ntile = 0, st_dead = 0;
     uint32_t st_rounds = 0;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
+    unsigned long long rp_collect = 0, rp_ref0 = 0, rp_replay = 0, rp_waitC = 0, rp_light = 0, rp_waitA = 0, r0 = 0, r1 = 0;
+#define RSTAMP(acc) do { r1 = __builtin_amdgcn_s_memtime(); acc += r1 - r0; r0 = r1; } while (0)
 #else
 #define STAMP(x)
+#define RSTAMP(acc)
 #endif
 
 #ifdef RBQ_STAMPS
     const unsigned long long st_loop0 = __builtin_amdgcn_s_memtime();
     unsigned long long st_tiles = 0, st_t0 = 0;
 #endif
+  for (;;) { // a second pass only after a tie on the sorted fast path
     while (true) {
         if (pos < ns && qcount < (uint32_t)kTileBlocks) {
             // ---------------------------------------------------------------- fill step: examine kWindow blocks
@@ -529,11 +566,12 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             if (scanner) {
                 // one lane per block: work item -> block summary + probe constants -> block-level bound
                 const float T = s_T;
-                const uint32_t idx = pos + wave * 64u + lane;
+                const uint32_t wslot = wave * 64u + lane;
+                const uint32_t idx = pos + wslot;
                 WorkItem w;
                 w.gblock = 0; w.rank_nvalid = 0;
                 bool live = false;
-                if (idx < ns) {
+                if (wslot < win && idx < ns) {
                     w = wl[idx];
                     live = true;
                     if (bound_ok) {
@@ -578,7 +616,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 lds_barrier(); // X2
                 qcount += total;
             }
-            pos += kWindow;
+            pos += win;
+            win = win * 2u < (uint32_t)kWindow ? win * 2u : (uint32_t)kWindow;
 #ifdef RBQ_STAMPS
             STAMP(st_b); st_fill += st_b - st_c;
 #endif
@@ -670,7 +709,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             }
         } else {
             // ---------------------------------------------------------------- replay wave (uniform control flow)
+            STAMP(r0);
             lds_barrier(); // A
+            RSTAMP(rp_waitA);
             // compaction in stream order: block by block, lane order within the block
             for (uint32_t b = half; b < (uint32_t)kTileBlocks; b += 2) {
                 uint32_t base = 0;
@@ -689,6 +730,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             // replays the examined stretch against the running threshold.
             struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
             auto cur_distk = [&]() -> float {
+                if (fast) return SortedTop::distk(rh, top_k);
                 return reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
                                 : (lh.len < top_k ? INFINITY : heap_d[0]);
             };
@@ -722,7 +764,23 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 if ((bt.mt >> lane) & 1ull) { v_d = __float_as_int(q_d[bt.e]); v_s = q_slot[bt.e]; }
                 unsigned long long todo = bt.mt;
                 n_skip += (bt.np - bt.p) - bt.ncol;
-                if (reg_heap) {
+                if (fast) {
+                    bool tie = false;
+                    float distk = SortedTop::distk(rh, top_k);
+                    while (todo) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(bt.v_lb, (int)j));
+                        if (lb >= distk) { ++n_skip; continue; }
+                        ++n_ext;
+                        const int dbits = __builtin_amdgcn_readlane(v_d, (int)j);
+                        if (!finite_f(__int_as_float(dbits))) continue;
+                        ++n_est;
+                        tie |= SortedTop::insert(rh, dbits, (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j), top_k);
+                        distk = SortedTop::distk(rh, top_k);
+                    }
+                    if (tie && lane == 0) s_restart = 1u;
+                } else if (reg_heap) {
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
@@ -770,27 +828,37 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                     replay(bt);
                     p = bt.np;
                 }
+                RSTAMP(rp_light);
             } else {
                 // heavy tile, software-pipelined: round 0 is refined by all 16 groups; from then on the scanners'
                 // 12 groups refine batch r+1 — collected with the threshold as it stands BEFORE batch r is
                 // replayed, i.e. a superset again — while this wave replays batch r.
+                STAMP(r0);
                 Batch cur = collect(0, (uint32_t)(kScanThreads / 16), cur_distk());
+                RSTAMP(rp_collect);
                 if (lane == 0) s_nbatch = cur.ncol;
                 lds_barrier(); // B_0
                 refine_batch(buf, cur.ncol, tid >> 4);
                 lds_barrier(); // C_0
+                RSTAMP(rp_ref0);
                 while (cur.np < S) {
                     const Batch nxt = collect(cur.np, (uint32_t)(kNScan * 4), cur_distk());
                     if (lane == 0) s_nbatch = nxt.ncol;
                     lds_barrier(); // B_r: the scanners start on batch r+1
+                    RSTAMP(rp_collect);
                     replay(cur);
+                    RSTAMP(rp_replay);
                     lds_barrier(); // C_r
+                    RSTAMP(rp_waitC);
                     cur = nxt;
                 }
                 replay(cur);
+                RSTAMP(rp_replay);
             }
-            if (lane == 0) s_T = reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
-                                          : (lh.len < top_k ? INFINITY : heap_d[0]);
+            {
+                const float tnew = cur_distk();
+                if (lane == 0) s_T = tnew;
+            }
             if (heavy) {
                 if (lane == 0) s_nbatch = kBatchDone;
                 lds_barrier(); // final B: helpers leave the tile, fresh T is visible
@@ -804,7 +872,23 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         ++tile;
     }
     lds_barrier(); // F: the replay wave has consumed the last tile
+    if (!s_restart) break;
+    __syncthreads(); // every wave has seen the flag
+    if (tid == 0) {
+        s_T = INFINITY; s_restart = 0;
+        if (P.heap_restarts) atomicAdd(P.heap_restarts, 1u);
+    }
+    fast = false;
+    pos = 0; qhead = 0; qcount = 0; tile = 0; win = (uint32_t)kTileBlocks;
+    n_skip = 0; n_ext = 0; n_est = 0;
+    rh.len = 0;
+    __syncthreads();
+  }
     if (!scanner) {
+        if (fast) { // already sorted ascending
+            if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
+            if (lane == 0) s_len = rh.len;
+        } else {
         if (reg_heap) { // spill the register heap to LDS for the final heap-sort
             if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
             lh.len = rh.len;
@@ -813,6 +897,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         if (lane == 0) {
             lh.into_sorted();
             s_len = lh.len;
+        }
         }
         if (lane != 0) { n_skip = 0; n_ext = 0; n_est = 0; } // uniform counters: report them once
     }
@@ -831,14 +916,30 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         P.out_scores[(size_t)q * top_k + i] = sc;
     }
 #ifdef RBQ_STAMPS
-    if (tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
+#if RBQ_STAMPS == 3
+    if (tid == 0 && P.diag) { // scanner wave 0: lookup time, wait at barrier A, live tiles
+        P.diag[(size_t)q * 3 + 0] = (st_look & 0xffffffffull) | (st_waitA << 32);
+        P.diag[(size_t)q * 3 + 1] = (unsigned long long)(st_ntile - st_dead) | ((unsigned long long)st_surv << 32);
+        P.diag[(size_t)q * 3 + 2] = (st_fill & 0xffffffffull) | ((unsigned long long)st_nheavy << 32);
+    }
+#endif
+    if (RBQ_STAMPS == 1 && tid == 0 && P.diag) { // diagnostic build: the diag slots carry cycle stamps of scanner wave 0 instead
         const unsigned long long st_total0 = st_total;
         st_total = __builtin_amdgcn_s_memtime() - st_total;
         P.diag[(size_t)q * 3 + 0] = (st_heavy & 0xffffffffull) | ((unsigned long long)st_rounds << 32);
         P.diag[(size_t)q * 3 + 1] = (st_total & 0xffffffffull) | (((st_loop0 - st_total0) & 0xffffull) << 32) | ((unsigned long long)(tile & 0xffff) << 48);
         P.diag[(size_t)q * 3 + 2] = (unsigned long long)(st_tiles & 0xffffffffull) | (st_fill << 32);
     }
-    if (wave == (uint32_t)kNScan && lane == 0) { P.out_counts[q] = len; }
+    if (wave == (uint32_t)kNScan && lane == 0) {
+        P.out_counts[q] = len;
+#if RBQ_STAMPS == 2
+        if (P.diag) {
+            P.diag[(size_t)q * 3 + 0] = (rp_collect & 0xffffffffull) | (rp_ref0 << 32);
+            P.diag[(size_t)q * 3 + 1] = (rp_replay & 0xffffffffull) | (rp_waitC << 32);
+            P.diag[(size_t)q * 3 + 2] = (rp_light & 0xffffffffull) | (rp_waitA << 32);
+        }
+#endif
+    }
     if (false) {
 #else
     if (wave == (uint32_t)kNScan && lane == 0) {

@@ -48,6 +48,8 @@ def lib():
         L.rbq_profile_scan_bytes.argtypes = [vp]
         L.rbq_debug_rank_fallbacks.restype = C.c_uint64
         L.rbq_debug_rank_fallbacks.argtypes = [vp]
+        L.rbq_debug_heap_restarts.restype = C.c_uint64
+        L.rbq_debug_heap_restarts.argtypes = [vp]
         L.rbq_debug_set_option.restype = C.c_int
         L.rbq_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int]
         L.rbq_strerror.restype = C.c_char_p
@@ -220,6 +222,9 @@ class IvfRabitqIndex:
 
     def rank_fallbacks(self):
         return lib().rbq_debug_rank_fallbacks(self._h)
+
+    def heap_restarts(self):
+        return lib().rbq_debug_heap_restarts(self._h)
 
     def profile_scan_bytes(self):
         return lib().rbq_profile_scan_bytes(self._h)

@@ -15,6 +15,14 @@ q = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).cpu().nu
 for _ in range(2):
     ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
 d = diag.astype(np.uint64)
+if os.environ.get('RBQ_STAMPS_MODE') == '3':
+    lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
+    print('scanner wave 0 cycles/query: lookups %.0f  waitA %.0f  live tiles %.1f  survivors %.0f  fill %.0f  heavy tiles %.1f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
+    sys.exit(0)
+if os.environ.get('RBQ_STAMPS_MODE') == '2':
+    lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
+    print('replay wave cycles/query: collect %.0f  round0 refine %.0f  replay %.0f  waitC %.0f  light tiles %.0f  waitA %.0f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
+    sys.exit(0)
 heavy = (d[:, 0] & 0xffffffff).astype(np.float64); rounds = (d[:, 0] >> 32).astype(np.float64); waitA = np.zeros(len(d)); ntile = dead = np.zeros(len(d))
 print('heavy refine rounds/query %.1f' % rounds.mean())
 total = (d[:, 1] & 0xffffffff).astype(np.float64); prolog = ((d[:, 1] >> 32) & 0xffff).astype(np.float64); ntiles = (d[:, 1] >> 48).astype(np.float64); nheavy = np.zeros(len(d))
