@@ -34,6 +34,39 @@ struct WorkItem {
     uint32_t gblock;      // global 32-vector block index
     uint32_t rank_nvalid; // (probe rank << 6) | number of real vectors in the block (1..32)
 };
+// Per-block factor ranges over the block's REAL vectors, computed once at index creation.  Every float op of
+// the epilogue is monotone in each operand, so evaluating it on these extremes brackets every lane's lower
+// bound: lbmin <= lb_v <= lbmax.  `usable` is 0 when any factor is non-finite (the block is then never skipped).
+struct BlockSummary {
+    float fadd_min, fadd_max, fres_min, fres_max, ferr_min, ferr_max;
+    uint32_t usable, pad;
+};
+// One entry of a query's block stream (probe order, block order within a list).  `lbmin` is the block-level
+// lower bound of this (query, block) pair — everything in it but the running threshold is known when the
+// stream is written, so the scan's fill step is one 16-byte load and one compare per block.
+struct StreamItem {
+    uint32_t gblock, rank_nvalid;
+    float lbmin; // -inf: never skip
+    uint32_t pad;
+};
+// Block-level bound: accu of any code lies in [amin, amax] and lb is monotone in accu (direction = sign of
+// f_rescale), so the epilogue's own operation sequence (compute_batch_distances_u16, AVX2 body: only the first
+// op is fused) evaluated on the extremes of every operand is <= lb of every real vector of the block.
+__device__ __forceinline__ float block_lbmin(const BlockSummary& bs, float g_add, float g_err, const QueryConsts& qc) {
+    const float tA = fmaf(qc.delta, qc.amin, qc.sum_vl) + qc.k1x;
+    const float tB = fmaf(qc.delta, qc.amax, qc.sum_vl) + qc.k1x;
+    const float r0 = bs.fres_min * tA, r1 = bs.fres_min * tB, r2 = bs.fres_max * tA, r3 = bs.fres_max * tB;
+    const float rmin = fminf(fminf(r0, r1), fminf(r2, r3)), rmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    float elo = bs.fadd_min + g_add;
+    elo = elo + rmin;
+    const float lbmin = elo - bs.ferr_max * g_err;
+    float ehi = bs.fadd_max + g_add;
+    ehi = ehi + rmax;
+    const float lbmax = ehi - bs.ferr_min * g_err;
+    const bool fin = isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3) && isfinite(lbmin) && isfinite(lbmax) &&
+                     isfinite(elo) && isfinite(ehi);
+    return (bs.usable && fin) ? lbmin : -INFINITY;
+}
 
 __device__ __forceinline__ int32_t total_key(float x) { // f32::total_cmp ordering key
     int32_t i = __float_as_int(x);
@@ -406,10 +439,12 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
                                                      const float* __restrict__ cent, uint32_t D,
                                                      const uint32_t* __restrict__ list_gb0,
                                                      const uint32_t* __restrict__ list_n,
-                                                     ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
+                                                     ProbeInfo* __restrict__ probe, StreamItem* __restrict__ wl,
                                                      uint64_t wl_stride, uint32_t* __restrict__ nstream,
                                                      unsigned long long* __restrict__ nvec_probed,
-                                                     unsigned long long* __restrict__ prof_total) {
+                                                     unsigned long long* __restrict__ prof_total,
+                                                     const QueryConsts* __restrict__ consts,
+                                                     const BlockSummary* __restrict__ bsum) {
     extern __shared__ __align__(16) unsigned char smraw[];
     uint64_t* sel = reinterpret_cast<uint64_t*>(smraw);
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)np2 * 8);
@@ -512,14 +547,18 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
     }
     __syncthreads();
     uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    const QueryConsts qc = consts[q];
     for (uint32_t r = r0; r < r1; ++r) {
         uint32_t cid = (uint32_t)(sel[r] & 0xffffffffu);
         uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
+        const ProbeInfo pi = probe[(size_t)q * nprobe + r]; // written by this thread above
         for (uint32_t b = 0; b < nb; ++b) {
             uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
-            WorkItem wi;
+            StreamItem wi;
             wi.gblock = gb + b;
             wi.rank_nvalid = (r << 6) | nv;
+            wi.lbmin = block_lbmin(bsum[gb + b], pi.g_add, pi.g_err, qc);
+            wi.pad = 0;
             wl[pos++] = wi;
         }
     }

@@ -137,11 +137,12 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
                                                           const QueryConsts* __restrict__ consts, float cnorm2_max,
                                                           const uint32_t* __restrict__ list_gb0,
                                                           const uint32_t* __restrict__ list_n,
-                                                          ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
+                                                          ProbeInfo* __restrict__ probe, StreamItem* __restrict__ wl,
                                                           uint64_t wl_stride, uint32_t* __restrict__ nstream,
                                                           unsigned long long* __restrict__ nvec_probed,
                                                           unsigned long long* __restrict__ prof_total,
-                                                          unsigned int* __restrict__ fallback_count, int force_fallback) {
+                                                          unsigned int* __restrict__ fallback_count, int force_fallback,
+                                                          const BlockSummary* __restrict__ bsum) {
     extern __shared__ __align__(16) unsigned char smraw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smraw);
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)cap2 * 8);
@@ -373,14 +374,18 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     }
     __syncthreads();
     uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    const QueryConsts qcs = consts[q];
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t cid = (uint32_t)(keys[r] & 0xffffffffu);
         const uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
+        const ProbeInfo pi = probe[(size_t)q * nprobe + r]; // written by this thread above
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
-            WorkItem wi;
+            StreamItem wi;
             wi.gblock = gb + b;
             wi.rank_nvalid = (r << 6) | nv;
+            wi.lbmin = block_lbmin(bsum[gb + b], pi.g_add, pi.g_err, qcs);
+            wi.pad = 0;
             wl[pos++] = wi;
         }
     }
@@ -396,8 +401,10 @@ __global__ __launch_bounds__(kThreads) void k_probes_given(const uint32_t* __res
                                                            const float* __restrict__ cent, uint32_t D,
                                                            const uint32_t* __restrict__ list_gb0,
                                                            const uint32_t* __restrict__ list_n,
-                                                           ProbeInfo* __restrict__ probe, WorkItem* __restrict__ wl,
-                                                           uint64_t wl_stride, uint32_t* __restrict__ nstream) {
+                                                           ProbeInfo* __restrict__ probe, StreamItem* __restrict__ wl,
+                                                           uint64_t wl_stride, uint32_t* __restrict__ nstream,
+                                                           const QueryConsts* __restrict__ consts,
+                                                           const BlockSummary* __restrict__ bsum) {
     extern __shared__ __align__(16) unsigned char smraw[];
     float* qrot = reinterpret_cast<float*>(smraw);
     uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
@@ -441,15 +448,19 @@ __global__ __launch_bounds__(kThreads) void k_probes_given(const uint32_t* __res
     }
     __syncthreads();
     uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    const QueryConsts qcs = consts[q];
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t cid = mine[r];
         if (cid >= nlist) continue;
         const uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
+        const ProbeInfo pi = probe[(size_t)q * max_lists + r];
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
-            WorkItem wi;
+            StreamItem wi;
             wi.gblock = gb + b;
             wi.rank_nvalid = (r << 6) | nv;
+            wi.lbmin = block_lbmin(bsum[gb + b], pi.g_add, pi.g_err, qcs);
+            wi.pad = 0;
             wl[pos++] = wi;
         }
     }

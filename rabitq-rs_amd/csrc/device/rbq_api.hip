@@ -389,9 +389,8 @@ int scan_stage(rbq_index* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, 
     ScanParams P;
     P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
     P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
-    P.bsum = (const BlockSummary*)ix->d_bsum;
     P.lut = (const uint8_t*)w->lut.p; P.rot = (const float*)w->rot.p; P.consts = (const QueryConsts*)w->consts.p;
-    P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const WorkItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
+    P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const StreamItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
     P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
     P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
     P.D = D; P.Dc = Dc; P.nprobe = probe_stride; P.top_k = top_k; P.metric = ix->metric;
@@ -429,7 +428,7 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
     if ((rc = w->consts.ensure(nq * sizeof(QueryConsts)))) return rc;
     if ((rc = w->scores.ensure(nq * (size_t)nlist * 4))) return rc;
     if ((rc = w->probe.ensure(nq * (size_t)nprobe * sizeof(ProbeInfo)))) return rc;
-    if ((rc = w->wl.ensure(nq * wl_stride * sizeof(WorkItem)))) return rc;
+    if ((rc = w->wl.ensure(nq * wl_stride * sizeof(StreamItem)))) return rc;
     if ((rc = w->nstream.ensure(nq * 4))) return rc;
     if ((rc = w->nvec.ensure(nq * 8))) return rc;
 
@@ -459,8 +458,9 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             hipLaunchKernelGGL(k_select, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (const float*)w->scores.p, nlist, nprobe,
                                np2, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
                                (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
-                               (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
-                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr);
+                               (StreamItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
+                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr,
+                               (const QueryConsts*)w->consts.p, (const BlockSummary*)ix->d_bsum);
             HIP_TRY(hipGetLastError());
         }
     } else {
@@ -488,10 +488,10 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             hipLaunchKernelGGL(k_select_mfma, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (float*)w->scores.p, nlist, nprobe,
                                cap2, row_in_lds, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
                                (const QueryConsts*)w->consts.p, ix->cnorm2_max, (const uint32_t*)ix->d_list_gb0,
-                               (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p, (WorkItem*)w->wl.p, wl_stride,
+                               (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p, (StreamItem*)w->wl.p, wl_stride,
                                (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
                                ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr, (unsigned int*)ix->d_fallbacks,
-                               ix->force_rank_fallback ? 1 : 0);
+                               ix->force_rank_fallback ? 1 : 0, (const BlockSummary*)ix->d_bsum);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -802,7 +802,7 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
             if ((r2 = d_lists.ensure(n * (size_t)max_lists * 4))) return r2;
             if ((r2 = d_cnts.ensure(n * 8))) return r2;
             if ((r2 = w->probe.ensure(n * (size_t)max_lists * sizeof(ProbeInfo)))) return r2;
-            if ((r2 = w->wl.ensure(n * wl_stride * sizeof(WorkItem)))) return r2;
+            if ((r2 = w->wl.ensure(n * wl_stride * sizeof(StreamItem)))) return r2;
             if ((r2 = w->nstream.ensure(n * 4))) return r2;
             if ((r2 = w->out_ids.ensure(n * top_k * 8))) return r2;
             if ((r2 = w->out_scores.ensure(n * top_k * 4))) return r2;
@@ -824,7 +824,8 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
                                    (const uint32_t*)d_lists.p, (const uint32_t*)d_cnts.p, max_lists, (uint32_t)ix->n_lists,
                                    (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
                                    (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
-                                   (WorkItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p);
+                                   (StreamItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (const QueryConsts*)w->consts.p,
+                                   (const BlockSummary*)ix->d_bsum);
                 HIP_TRY(hipGetLastError());
             }
             if ((r2 = scan_stage(ix, w, n, max_lists, top_k, wl_stride, nullptr, 0, (uint64_t*)w->out_ids.p,

@@ -22,26 +22,17 @@
 
 namespace rbq {
 
-// Per-block factor ranges over the block's REAL vectors, computed once at index creation.  Every float op of
-// the epilogue is monotone in each operand, so evaluating it on these extremes brackets every lane's lower
-// bound: lbmin <= lb_v <= lbmax.  `usable` is 0 when any factor is non-finite (the block is then never skipped).
-struct BlockSummary {
-    float fadd_min, fadd_max, fres_min, fres_max, ferr_min, ferr_max;
-    uint32_t usable, pad;
-};
-
 struct ScanParams {
     const uint8_t* blocks;   // [n_blocks][4Dc + 384]: lane-major sign codes | f_add[32] | f_rescale[32] | f_error[32]
     const uint64_t* ids;     // [n_blocks*32]
     const uint8_t* ex_codes; // [n_blocks*32][ex_bytes_dev]: lane-major ex codes, see ex_w4()
     const float* f_add_ex;   // [n_blocks*32]
     const float* f_rescale_ex;
-    const BlockSummary* bsum; // [n_blocks] factor ranges of each block (block-level lower bound)
     const uint8_t* lut;      // [nq][4Dc] (pair-swapped codebook order); Dc = D rounded up to x64
     const float* rot;        // [nq][D]
     const QueryConsts* consts;
     const ProbeInfo* probe;  // [nq][nprobe]
-    const WorkItem* wl;      // [nq][wl_stride]
+    const StreamItem* wl;    // [nq][wl_stride]
     const uint32_t* nstream; // [nq]
     const uint32_t* filter;  // dense bitset or null
     uint64_t filter_nbits;
@@ -457,7 +448,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     }
     const QueryConsts qc = P.consts[q];
     const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
-    const WorkItem* wl = P.wl + (size_t)q * P.wl_stride;
+    const StreamItem* wl = P.wl + (size_t)q * P.wl_stride;
     const uint32_t ns = P.nstream[q];
     __syncthreads();
 
@@ -564,7 +555,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             // ---------------------------------------------------------------- fill step: examine kWindow blocks
             STAMP(st_c);
             if (scanner) {
-                // one lane per block: work item -> block summary + probe constants -> block-level bound
+                // one lane per block: stream entry (with its precomputed block-level bound) vs the threshold
                 const float T = s_T;
                 const uint32_t wslot = wave * 64u + lane;
                 const uint32_t idx = pos + wslot;
@@ -572,27 +563,12 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 w.gblock = 0; w.rank_nvalid = 0;
                 bool live = false;
                 if (wslot < win && idx < ns) {
-                    w = wl[idx];
+                    const StreamItem si = wl[idx];
+                    w.gblock = si.gblock; w.rank_nvalid = si.rank_nvalid;
                     live = true;
-                    if (bound_ok) {
-                        const BlockSummary bs = P.bsum[w.gblock];
-                        const ProbeInfo pi = probe[w.rank_nvalid >> 6];
-                        const float tA = fmaf(qc.delta, qc.amin, qc.sum_vl) + qc.k1x;
-                        const float tB = fmaf(qc.delta, qc.amax, qc.sum_vl) + qc.k1x;
-                        const float r0 = bs.fres_min * tA, r1 = bs.fres_min * tB, r2 = bs.fres_max * tA, r3 = bs.fres_max * tB;
-                        const float rmin = fminf(fminf(r0, r1), fminf(r2, r3)), rmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-                        float elo = bs.fadd_min + pi.g_add;
-                        elo = elo + rmin;
-                        const float lbmin = elo - bs.ferr_max * pi.g_err;
-                        float ehi = bs.fadd_max + pi.g_add;
-                        ehi = ehi + rmax;
-                        const float lbmax = ehi - bs.ferr_min * pi.g_err;
-                        const bool fin = finite_f(r0) && finite_f(r1) && finite_f(r2) && finite_f(r3) && finite_f(lbmin) &&
-                                         finite_f(lbmax) && finite_f(elo) && finite_f(ehi);
-                        if (bs.usable && fin && lbmin >= T) {
-                            live = false;
-                            if (count_skips) n_skip += w.rank_nvalid & 63u;
-                        }
+                    if (bound_ok && si.lbmin >= T) { // block_lbmin(): no real vector of the block can pass
+                        live = false;
+                        if (count_skips) n_skip += w.rank_nvalid & 63u;
                     }
                 }
                 const unsigned long long livemask = __ballot(live);
