@@ -455,19 +455,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t n_skip = 0, n_ext = 0, n_est = 0; // n_skip: every thread; n_ext/n_est: replay wave (uniform)
     const bool count_skips = P.diag != nullptr;
 
-    // refine survivors i = g0, g0+gstep, ... of tile buffer `buf`; 16 lanes per survivor
-    auto refine_finish = [&](uint32_t e, uint32_t sl, float sacc) {
-        sacc = group16_reduce(sacc);
-        if ((tid & 15u) == 0) {
-            float tt2 = qc.scale * q_ip[e];
-            tt2 = tt2 + sacc;
-            tt2 = tt2 + qc.kbx;
-            const float a = P.f_add_ex[sl] + q_gadd[e];
-            const float m = P.f_rescale_ex[sl] * tt2;
-            q_d[e] = a + m;
-        }
-    };
-    // group `g` (16 lanes) refines the survivor at queue position s_batch[g] of tile buffer `buf`
+    // group `g` (16 lanes) refines the survivor at queue position s_batch[g] of tile buffer `buf`.  The ex
+    // factors are requested together with the code units, not after the dot product.
     auto refine_batch = [&](uint32_t buf, uint32_t nb, uint32_t g) {
         const uint32_t gl = tid & 15u;
         if (g < nb) {
@@ -475,14 +464,27 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             const uint32_t sl = q_slot[e];
             const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
             float sacc;
+            float fa, fr;
             if (nunits <= (uint32_t)kExRegUnits) {
                 uint4 u[kExRegUnits];
                 ex_load_all(u, ex, gl, nunits);
+                fa = P.f_add_ex[sl]; fr = P.f_rescale_ex[sl];
+                asm volatile("" : "+v"(fa), "+v"(fr)); // issue the loads here
                 sacc = ex_bits == 6 ? ex_dot_all<6>(u, s_q, gl, nunits) : ex_dot_all<2>(u, s_q, gl, nunits);
             } else {
+                fa = P.f_add_ex[sl]; fr = P.f_rescale_ex[sl];
+                asm volatile("" : "+v"(fa), "+v"(fr));
                 sacc = ex_bits == 6 ? ex_dot_units<6>(ex, s_q, gl, nunits) : ex_dot_units<2>(ex, s_q, gl, nunits);
             }
-            refine_finish(e, sl, sacc);
+            sacc = group16_reduce(sacc);
+            if (gl == 0) {
+                float tt2 = qc.scale * q_ip[e];
+                tt2 = tt2 + sacc;
+                tt2 = tt2 + qc.kbx;
+                const float a = fa + q_gadd[e];
+                const float m = fr * tt2;
+                q_d[e] = a + m;
+            }
         }
     };
 
@@ -741,20 +743,35 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 unsigned long long todo = bt.mt;
                 n_skip += (bt.np - bt.p) - bt.ncol;
                 if (fast) {
+                    // Everything here is wave-uniform; ballots and readfirstlane say so to the compiler, which
+                    // otherwise keeps the state in VGPRs and branches through the exec mask.
+                    uint32_t len_s = RegHeap::uni(rh.len);
                     bool tie = false;
-                    float distk = SortedTop::distk(rh, top_k);
+                    int dk = len_s < top_k ? 0x7f800000 : __builtin_amdgcn_readlane(rh.hd, (int)RegHeap::uni(top_k - 1u));
+                    uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
                         const float lb = __int_as_float(__builtin_amdgcn_readlane(bt.v_lb, (int)j));
-                        if (lb >= distk) { ++n_skip; continue; }
-                        ++n_ext;
+                        if (__ballot(lb >= __int_as_float(dk)) != 0ull) { ++c_skip; continue; }
+                        ++c_ext;
                         const int dbits = __builtin_amdgcn_readlane(v_d, (int)j);
-                        if (!finite_f(__int_as_float(dbits))) continue;
-                        ++n_est;
-                        tie |= SortedTop::insert(rh, dbits, (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j), top_k);
-                        distk = SortedTop::distk(rh, top_k);
+                        if ((dbits & 0x7f800000) == 0x7f800000) continue; // non-finite
+                        ++c_est;
+                        const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
+                        const int ke = RegHeap::key(dbits), k = RegHeap::key(rh.hd);
+                        const bool in = lane < len_s;
+                        tie |= __ballot(in && k == ke) != 0ull;
+                        const uint32_t ipos = (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
+                        const int sd = __builtin_amdgcn_update_dpp(0, rh.hd, 0x138, 0xf, 0xf, false);      // wave_shr:1
+                        const int ss = __builtin_amdgcn_update_dpp(0, (int)rh.hs, 0x138, 0xf, 0xf, false);
+                        rh.hd = lane == ipos ? dbits : (lane > ipos ? sd : rh.hd);
+                        rh.hs = lane == ipos ? slot : (lane > ipos ? (uint32_t)ss : rh.hs);
+                        len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
+                        dk = len_s < top_k ? 0x7f800000 : __builtin_amdgcn_readlane(rh.hd, (int)RegHeap::uni(top_k - 1u));
                     }
+                    rh.len = len_s;
+                    n_skip += c_skip; n_ext += c_ext; n_est += c_est;
                     if (tie && lane == 0) s_restart = 1u;
                 } else if (reg_heap) {
                     while (todo) {
