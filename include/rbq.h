@@ -170,10 +170,14 @@ uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
  * re-run inside the scan kernel with the exact BinaryHeap emulation (src/ivf.rs:2078-2105 pushes into a
  * std BinaryHeap, whose tie behaviour depends on its layout). Diagnostic. */
 uint64_t rbq_debug_heap_restarts(const rbq_index* idx);
+/* Diagnostic: copy an intermediate buffer ("rot", "lut", "consts", "scores", "probe", "nstream", "wl") of the
+ * workspace that rbq_search_batch_device bound to `hip_stream`; the caller has synchronised that stream. */
+int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name, void* dst, uint64_t bytes);
 /* Diagnostic switches; results are identical under every setting, only the work done changes:
  *   "block_bound" 0      stream every probed block (no block-level lower-bound skipping)
  *   "exact_rank" 1       rank all nq x nlist pairs in canonical order instead of the MFMA shortlist
  *   "force_rank_fallback" 1   send every query through the shortlist's all-lists fallback
+ *   "f32_rank" 1         approximate list scores from the f32 MFMA GEMM instead of the split-bf16 one
  *   "exact_heap" 1       keep the top-k in the BinaryHeap emulation from the first candidate (no sorted fast path) */
 int rbq_debug_set_option(rbq_index* idx, const char* name, int value);
 

@@ -92,11 +92,32 @@ __device__ __forceinline__ void fht_lds(float* a, uint32_t n, uint32_t tid) {
     }
 }
 
+// round-to-nearest-even f32 -> bf16 bits (inf stays inf; NaN stays NaN)
+__host__ __device__ inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+// x = hi + lo + r: the subtraction is exact (hi is x rounded to 8 significant bits)
+__host__ __device__ inline void bf16_split(float x, uint16_t& hi, uint16_t& lo) {
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - bf16_to_f32(hi));
+}
+
 __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ queries, uint32_t dim, uint32_t D,
                                                    uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
                                                    uint32_t trunc, float fac, uint32_t ex_bits,
                                                    float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
-                                                   QueryConsts* __restrict__ consts) {
+                                                   QueryConsts* __restrict__ consts,
+                                                   uint16_t* __restrict__ rot_hi, uint16_t* __restrict__ rot_lo) {
     extern __shared__ __align__(16) float sm[];
     float* x = sm;         // [D]
     float* y = sm + D;     // [D] (matrix rotator input)
@@ -160,7 +181,15 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         __syncthreads();
     }
 
-    for (uint32_t i = tid; i < D; i += kThreads) rot_out[(size_t)q * D + i] = x[i];
+    for (uint32_t i = tid; i < D; i += kThreads) {
+        rot_out[(size_t)q * D + i] = x[i];
+        if (rot_hi) { // split-bf16 image for k_rank_bf16
+            uint16_t h, l;
+            bf16_split(x[i], h, l);
+            rot_hi[(size_t)q * D + i] = h;
+            rot_lo[(size_t)q * D + i] = l;
+        }
+    }
 
     // QueryPrecomputed::new — strictly sequential sums (Rust iter().sum() folds from -0.0)
     if (tid == 0) {

@@ -3,13 +3,20 @@
 // Reference: search_fastscan's centroid ranking (src/ivf.rs:1782-1835) with math::l2_distance_sqr / dot in
 // their AVX2 lane order (src/math.rs:154-245).  Ranking all nq x nlist pairs in that exact order costs
 // 3*nq*nlist*D unfused VALU ops; instead
-//   k_rank_mfma    one f32 MFMA GEMM (v_mfma_f32_32x32x2_f32, exact f32 FMA chain) gives APPROXIMATE scores
+//   k_rank_bf16    one split-bf16 MFMA GEMM gives APPROXIMATE scores
 //                  A(q,c) = |q|^2 + |c|^2 - 2 q.c   (L2)   or   q.c   (IP)
+//                  with x = hi + lo + r (hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x|) and
+//                  q.c ~ qh.ch + qh.cl + ql.ch on v_mfma_f32_32x32x16_bf16 (products exact, f32 accumulate);
+//                  the dropped terms are <= 3.01 * 2^-16 * sum|q_i||c_i| <= 1.51 * 2^-16 (|q|^2 + |c|^2)
+//   k_rank_mfma    the same scores from one f32 MFMA GEMM (v_mfma_f32_32x32x2_f32), used when D % 64 != 0
 //   k_select_mfma  per query: nprobe-th approximate score tau, shortlist {c : A(c) within 2*eps of tau},
 //                  EXACT canonical-order scores for the shortlist only, exact (score, cid) sort.
 // eps bounds |A - canonical| rigorously (standard rounding-error model, n = D, u = 2^-24):
 //   |canonical - s*| <= gamma_n s*  (positive terms),  |A - s*| <= 2 gamma_{n+2} (|q|^2 + |c|^2)
 //   =>  |A - canonical| <= 4 gamma_{n+2} (|q|^2 + |c|^2)   (s* <= 2(|q|^2+|c|^2));  eps uses 6 n u (..), > that.
+// The split-bf16 GEMM accumulates 3n exact products: 2 gamma_{3n+2} * (sum|q_i||c_i| <= (|q|^2+|c|^2)/2) plus the
+// norm terms stays below 4 n u (|q|^2+|c|^2) even if the MFMA adder truncates (u -> 2u), and the split itself
+// adds 2 * 1.51 * 2^-16 (|q|^2+|c|^2) to the L2 score: eps = (6 n u + 4 * 2^-16)(|q|^2 + max|c|^2).
 // Any true top-nprobe member has canonical <= (largest canonical among the approximate top-nprobe) <= tau+eps,
 // hence A <= tau + 2 eps: it is in the shortlist.  If the shortlist overflows its LDS capacity (many
 // near-equal scores) or a score is not finite, the query falls back to canonical scores for ALL lists.
@@ -65,6 +72,146 @@ __global__ __launch_bounds__(256) void k_rank_mfma(const float* __restrict__ rot
 #pragma unroll
                 for (int b = 0; b < TW; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < TW; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b) {
+            const uint32_t c = c0 + wn * 32 * TW + b * 32 + (lane & 31u);
+            const float cn = (METRIC == 0 && c < nlist) ? cnorm2[c] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t qi = q0 + wm * 32 * TW + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qi < nq && c < nlist) {
+                    const float dot = acc[a][b][r];
+                    float v = dot;
+                    if (METRIC == 0) {
+                        const float qn = consts[qi].qnorm2;
+                        v = fmaf(-2.0f, dot, qn + cn);
+                    }
+                    scores[(size_t)qi * nlist + c] = v;
+                }
+            }
+        }
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_x8(bf16x8 a, bf16x8 b, f32x16 c) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 as = __builtin_bit_cast(s16x8, a), bs = __builtin_bit_cast(s16x8, b);
+    const s16x4 a0 = {as[0], as[1], as[2], as[3]}, a1 = {as[4], as[5], as[6], as[7]};
+    const s16x4 b0 = {bs[0], bs[1], bs[2], bs[3]}, b1 = {bs[4], bs[5], bs[6], bs[7]};
+    c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b1, c, 0, 0, 0);
+}
+
+// Split-bf16 GEMM: 64*TW x 64*TW tile per 256-thread workgroup, K slabs of 64 staged through LDS (rows padded to
+// 144 bytes: the 16 lanes of a ds_read_b128 group then hit 16 distinct 4-bank sets), next slab prefetched into
+// registers while the current one feeds the MFMAs.  D % 64 == 0.
+// dynamic LDS: Ah | Al | Bh | Bl, each [64*TW][144 B]
+template <int METRIC, int TW>
+__global__ __launch_bounds__(256) void k_rank_bf16(const uint16_t* __restrict__ rot_hi, const uint16_t* __restrict__ rot_lo,
+                                                   const uint16_t* __restrict__ cent_hi, const uint16_t* __restrict__ cent_lo,
+                                                   const QueryConsts* __restrict__ consts,
+                                                   const float* __restrict__ cnorm2, uint32_t nq, uint32_t nlist,
+                                                   uint32_t D, float* __restrict__ scores) {
+    constexpr int BM = 64 * TW, BK = 64, LDB = BK * 2 + 16, SEG = BK / 8, NL = BM * SEG / 256; // NL 16-byte loads per thread and array
+    extern __shared__ __align__(16) unsigned char smraw[];
+    unsigned char* sAh = smraw;
+    unsigned char* sAl = sAh + BM * LDB;
+    unsigned char* sBh = sAl + BM * LDB;
+    unsigned char* sBl = sBh + BM * LDB;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w >> 1, wn = w & 1u;
+    const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BM;
+    f32x16 acc[TW][TW];
+#pragma unroll
+    for (int a = 0; a < TW; ++a)
+#pragma unroll
+        for (int b = 0; b < TW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // per-thread source rows (clamped: rows past the end compute scores that are never stored) and LDS slots
+    const unsigned char* ga_h[NL];
+    const unsigned char* ga_l[NL];
+    const unsigned char* gb_h[NL];
+    const unsigned char* gb_l[NL];
+    uint32_t so[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const uint32_t idx = tid + 256u * i, row = idx / SEG, seg = idx % SEG;
+        const uint32_t ra = q0 + row < nq ? q0 + row : nq - 1u, rb = c0 + row < nlist ? c0 + row : nlist - 1u;
+        ga_h[i] = reinterpret_cast<const unsigned char*>(rot_hi) + (size_t)ra * D * 2 + seg * 16;
+        ga_l[i] = reinterpret_cast<const unsigned char*>(rot_lo) + (size_t)ra * D * 2 + seg * 16;
+        gb_h[i] = reinterpret_cast<const unsigned char*>(cent_hi) + (size_t)rb * D * 2 + seg * 16;
+        gb_l[i] = reinterpret_cast<const unsigned char*>(cent_lo) + (size_t)rb * D * 2 + seg * 16;
+        so[i] = row * LDB + seg * 16;
+    }
+    u32x4 pah[NL], pal[NL], pbh[NL], pbl[NL]; // native vectors: the HIP uint4 struct kept these arrays in scratch
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i]);
+        pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i]);
+        pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i]);
+        pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i]);
+    }
+    for (uint32_t k0 = 0; k0 < D; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            *reinterpret_cast<u32x4*>(sAh + so[i]) = pah[i];
+            *reinterpret_cast<u32x4*>(sAl + so[i]) = pal[i];
+            *reinterpret_cast<u32x4*>(sBh + so[i]) = pbh[i];
+            *reinterpret_cast<u32x4*>(sBl + so[i]) = pbl[i];
+        }
+        __syncthreads();
+        {
+            const uint32_t kn = k0 + BK < D ? k0 + BK : k0; // last slab: reload (unused)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i] + (size_t)kn * 2);
+                pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i] + (size_t)kn * 2);
+                pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i] + (size_t)kn * 2);
+                pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i] + (size_t)kn * 2);
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < BK / 16; ++kc) {
+            // A/B operand of 32x32x16: lane l holds row (l & 31), k = 8 * (l >> 5) .. + 7
+            const uint32_t fo = (lane & 31u) * LDB + kc * 32 + (lane >> 5) * 16;
+            bf16x8 ah[TW], al[TW], bh[TW], bl[TW];
+#pragma unroll
+            for (int a = 0; a < TW; ++a) {
+                const uint32_t ra = (wm * 32 * TW + a * 32) * LDB + fo, rb = (wn * 32 * TW + a * 32) * LDB + fo;
+                ah[a] = *reinterpret_cast<const bf16x8*>(sAh + ra);
+                al[a] = *reinterpret_cast<const bf16x8*>(sAl + ra);
+                bh[a] = *reinterpret_cast<const bf16x8*>(sBh + rb);
+                bl[a] = *reinterpret_cast<const bf16x8*>(sBl + rb);
+            }
+#pragma unroll
+            for (int a = 0; a < TW; ++a)
+#pragma unroll
+                for (int b = 0; b < TW; ++b) {
+                    // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used: with it, workgroups of OTHER
+                    // kernels resident on the same SIMDs (k_prep of a neighbouring stream) computed wrong values —
+                    // one 16-lane pass of a quantisation result at a time, tools/stress3.py — on this hardware pool.
+                    // The K=8 form below is clean under the same stress (tests/test_gpu_parity.py multi-stream test).
+#ifdef RBQ_MFMA_X16
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+#else
+                    // two K=8 steps per 8-element fragment: both operands use the same k subset per lane half
+                    acc[a][b] = mfma_x8(al[a], bh[b], acc[a][b]);
+                    acc[a][b] = mfma_x8(ah[a], bl[b], acc[a][b]);
+                    acc[a][b] = mfma_x8(ah[a], bh[b], acc[a][b]);
+#endif
+                }
         }
         __syncthreads();
     }
@@ -200,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     }
     // 2. shortlist: approximate score within 2*eps of tau
     const QueryConsts qc = consts[q];
-    const float eps = 6.0f * (float)D * 5.9604645e-8f * (qc.qnorm2 + cnorm2_max) * 1.001f;
+    const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + cnorm2_max) * 1.001f;
     uint32_t cut = 0xffffffffu;
     if (!all) {
         // back from ordered key to the score value

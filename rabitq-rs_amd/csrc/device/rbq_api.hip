@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,9 +59,9 @@ struct DevBuf {
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_ids, out_scores, out_counts, diag, filter;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_ids, out_scores, out_counts, diag, filter, rot_hi, rot_lo;
     void release() {
-        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &out_ids, &out_scores,
+        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_ids, &out_scores,
                           &out_counts, &diag, &filter})
             b->release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -85,9 +86,10 @@ struct rbq_index {
     float fac = 1.0f;
     // device arrays
     void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
-         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr;
+         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr, *d_cent_hi = nullptr, *d_cent_lo = nullptr;
     float cnorm2_max = 0.0f;
     bool no_block_bound = false; // rbq_debug_set_option("block_bound", 0)
+    bool f32_rank = false;       // rbq_debug_set_option("f32_rank", 1): f32 MFMA GEMM instead of the split-bf16 one
     bool exact_heap = false;     // rbq_debug_set_option("exact_heap", 1): BinaryHeap emulation from the first candidate
     bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
     bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
@@ -109,7 +111,7 @@ void free_index(rbq_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (void* p : {ix->d_rot_blob, ix->d_centroids, ix->d_blocks, ix->d_ids, ix->d_ex, ix->d_fadd_ex, ix->d_fres_ex,
-                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum, ix->d_cnorm2, ix->d_fallbacks})
+                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum, ix->d_cnorm2, ix->d_fallbacks, ix->d_cent_hi, ix->d_cent_lo})
         if (p) (void)hipFree(p);
     for (Workspace* w : ix->pool) { w->release(); delete w; }
     for (auto& kv : ix->stream_ws) { kv.second->release(); delete kv.second; }
@@ -318,6 +320,9 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
         }
         ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
         UP(d_cnorm2, cn);
+        std::vector<uint16_t> ch(cent.size()), cl(cent.size()); // split-bf16 image of the centroids (k_rank_bf16)
+        for (size_t i = 0; i < cent.size(); ++i) bf16_split(cent[i], ch[i], cl[i]);
+        UP(d_cent_hi, ch); UP(d_cent_lo, cl);
         std::vector<unsigned int> z(2, 0); // [0] rank fallbacks, [1] heap restarts
         UP(d_fallbacks, z);
         const char* e = std::getenv("RBQ_EXACT_RANK");
@@ -431,13 +436,19 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
     if ((rc = w->wl.ensure(nq * wl_stride * sizeof(StreamItem)))) return rc;
     if ((rc = w->nstream.ensure(nq * 4))) return rc;
     if ((rc = w->nvec.ensure(nq * 8))) return rc;
+    const bool split_rank = !ix->exact_rank && !ix->f32_rank && D % 64 == 0; // k_rank_bf16 (else k_rank_mfma)
+    if (split_rank) {
+        if ((rc = w->rot_hi.ensure(nq * D * 2))) return rc;
+        if ((rc = w->rot_lo.ensure(nq * D * 2))) return rc;
+    }
 
     {
         ProfScope ps(ix, 0, stream);
         const size_t lds = (size_t)D * 4 * 2;
         hipLaunchKernelGGL(k_prep, dim3((uint32_t)nq), dim3(kThreads), lds, stream, d_queries, ix->dim, D, Dc, (int)ix->rotator,
                            (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p,
-                           (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p);
+                           (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p, split_rank ? (uint16_t*)w->rot_hi.p : nullptr,
+                           split_rank ? (uint16_t*)w->rot_lo.p : nullptr);
         HIP_TRY(hipGetLastError());
     }
     if (ix->exact_rank) {
@@ -465,16 +476,36 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         }
     } else {
         {
-            ProfScope ps(ix, 1, stream); // approximate scores: one f32 MFMA GEMM
+            ProfScope ps(ix, 1, stream); // approximate scores: one MFMA GEMM
             const bool big = (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
             const uint32_t T = big ? 128u : 64u;
             dim3 grid((nlist + T - 1) / T, (uint32_t)((nq + T - 1) / T));
+            if (split_rank) {
+                const size_t lds = (size_t)T * 144 * 4;
+#define RBQ_LAUNCH_RANKB(M, TW)                                                                                        \
+    do {                                                                                                               \
+        static std::atomic<int> attr_dev_mask{0}; /* once per device: the call is slow and serialises launches */      \
+        if (lds > 48 * 1024 && !(attr_dev_mask.load() & (1 << ix->device))) {                                          \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_bf16<M, TW>),                            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+            attr_dev_mask.fetch_or(1 << ix->device);                                                                   \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_rank_bf16<M, TW>), grid, dim3(256), lds, stream, (const uint16_t*)w->rot_hi.p,           \
+                           (const uint16_t*)w->rot_lo.p, (const uint16_t*)ix->d_cent_hi, (const uint16_t*)ix->d_cent_lo, \
+                           (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2, (uint32_t)nq, nlist, D,       \
+                           (float*)w->scores.p);                                                                       \
+    } while (0)
+                if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANKB(0, 2); else RBQ_LAUNCH_RANKB(0, 1); }
+                else { if (big) RBQ_LAUNCH_RANKB(1, 2); else RBQ_LAUNCH_RANKB(1, 1); }
+#undef RBQ_LAUNCH_RANKB
+            } else {
 #define RBQ_LAUNCH_RANK(M, TW)                                                                                         \
     hipLaunchKernelGGL((k_rank_mfma<M, TW>), grid, dim3(256), 0, stream, (const float*)w->rot.p,                       \
                        (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,   \
                        (uint32_t)nq, nlist, D, (float*)w->scores.p)
             if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANK(0, 2); else RBQ_LAUNCH_RANK(0, 1); }
             else { if (big) RBQ_LAUNCH_RANK(1, 2); else RBQ_LAUNCH_RANK(1, 1); }
+            }
 #undef RBQ_LAUNCH_RANK
             HIP_TRY(hipGetLastError());
         }
@@ -815,7 +846,8 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
                 ProfScope ps(ix, 0, st);
                 hipLaunchKernelGGL(k_prep, dim3((uint32_t)n), dim3(kThreads), (size_t)D * 4 * 2, st, (const float*)w->queries.p, ix->dim,
                                    D, Dc, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, 0u,
-                                   (float*)w->rot.p, (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p);
+                                   (float*)w->rot.p, (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p, (uint16_t*)nullptr,
+                                   (uint16_t*)nullptr);
                 HIP_TRY(hipGetLastError());
             }
             {
@@ -890,6 +922,7 @@ int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
     if (!std::strcmp(name, "block_bound")) { ix->no_block_bound = value == 0; return RBQ_OK; }
     if (!std::strcmp(name, "exact_rank")) { ix->exact_rank = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "exact_heap")) { ix->exact_heap = value != 0; return RBQ_OK; }
+    if (!std::strcmp(name, "f32_rank")) { ix->f32_rank = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "force_rank_fallback")) { ix->force_rank_fallback = value != 0; return RBQ_OK; }
     return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
 }
@@ -900,6 +933,30 @@ uint64_t rbq_debug_rank_fallbacks(const rbq_index* ix) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(&v, ix->d_fallbacks, 4, hipMemcpyDeviceToHost);
     return v;
+}
+
+/* Diagnostic: copy an intermediate buffer of the workspace bound to `hip_stream` (after the caller synchronised). */
+int rbq_debug_copy_workspace(rbq_index* ix, void* hip_stream, const char* name, void* dst, uint64_t bytes) {
+    if (!ix || !name || !dst) return RBQ_INVALID_CONFIG;
+    Workspace* w = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ix->mu);
+        auto it = ix->stream_ws.find((hipStream_t)hip_stream);
+        if (it != ix->stream_ws.end()) w = it->second;
+    }
+    if (!w) return fail(RBQ_INVALID_CONFIG, "no workspace for this stream");
+    DevBuf* b = nullptr;
+    if (!std::strcmp(name, "rot")) b = &w->rot;
+    else if (!std::strcmp(name, "lut")) b = &w->lut;
+    else if (!std::strcmp(name, "consts")) b = &w->consts;
+    else if (!std::strcmp(name, "scores")) b = &w->scores;
+    else if (!std::strcmp(name, "probe")) b = &w->probe;
+    else if (!std::strcmp(name, "nstream")) b = &w->nstream;
+    else if (!std::strcmp(name, "wl")) b = &w->wl;
+    if (!b || !b->p || bytes > b->cap) return fail(RBQ_INVALID_CONFIG, "unknown buffer or size");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));
+    return RBQ_OK;
 }
 
 uint64_t rbq_debug_heap_restarts(const rbq_index* ix) {

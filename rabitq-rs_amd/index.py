@@ -48,6 +48,8 @@ def lib():
         L.rbq_profile_scan_bytes.argtypes = [vp]
         L.rbq_debug_rank_fallbacks.restype = C.c_uint64
         L.rbq_debug_rank_fallbacks.argtypes = [vp]
+        L.rbq_debug_copy_workspace.restype = C.c_int
+        L.rbq_debug_copy_workspace.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint64]
         L.rbq_debug_heap_restarts.restype = C.c_uint64
         L.rbq_debug_heap_restarts.argtypes = [vp]
         L.rbq_debug_set_option.restype = C.c_int
@@ -222,6 +224,11 @@ class IvfRabitqIndex:
 
     def rank_fallbacks(self):
         return lib().rbq_debug_rank_fallbacks(self._h)
+
+    def debug_copy_workspace(self, stream, name, out):
+        """Diagnostic: copy an intermediate device buffer of `stream`'s workspace into the numpy array `out`."""
+        _check(lib().rbq_debug_copy_workspace(self._h, C.c_void_p(stream), name.encode(), out.ctypes.data, out.nbytes))
+        return out
 
     def heap_restarts(self):
         return lib().rbq_debug_heap_restarts(self._h)

@@ -87,6 +87,29 @@ def test_duplicate_vectors_exact_ties():
     idx = rq.IvfRabitqIndex.from_built(built)
     _compare(built, idx, base[:48], 10, 6)
     _compare(built, idx, base[:16], 3, 12)
+    # the sorted-run fast path must have noticed the bit-identical distances and re-run those queries with the
+    # exact BinaryHeap emulation; forcing that emulation from the start gives the same answer
+    assert idx.heap_restarts() > 0
+    idx.set_option("exact_heap", 1)
+    before = idx.heap_restarts()
+    _compare(built, idx, base[:48], 10, 6)
+    assert idx.heap_restarts() == before
+    idx.close()
+
+
+def test_rank_kernels_agree():
+    """Split-bf16 GEMM shortlist, f32 GEMM shortlist and the exact all-pairs ranking select the same probes
+    (ids and diagnostics equal the oracle's), and the shortlist never needs its fallback on ordinary data."""
+    data, built = build_index(n=20000, dim=256, nlist=256, total_bits=7, seed=17)
+    q = make_dataset(200, 256, 32, 18)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    _compare(built, idx, q, 10, 32)
+    assert idx.rank_fallbacks() == 0
+    idx.set_option("f32_rank", 1)
+    _compare(built, idx, q, 10, 32)
+    assert idx.rank_fallbacks() == 0
+    idx.set_option("exact_rank", 1)
+    _compare(built, idx, q, 10, 32)
     idx.close()
 
 
@@ -266,4 +289,35 @@ def test_mstg_posting_scan_rejects_rotated_index():
     with pytest.raises(rq.RabitqError) as e:
         idx.posting_scan(data[:2], 5, np.zeros((2, 2), np.uint32), np.ones(2, np.uint32))
     assert e.value.kind == "InvalidConfig"
+    idx.close()
+
+
+def test_concurrent_streams_match_oracle():
+    """rbq_search_batch_device on several caller streams at once (bench.py's pipelining): every stream's result
+    equals the oracle's.  Kernels of different streams share CUs and SIMDs here, which once exposed a
+    cross-kernel corruption (see rank_mfma.hpp, mfma_x8) that no single-stream test can see."""
+    import torch
+    dev = torch.device("cuda", 0)
+    data, built = build_index(n=60000, dim=960, nlist=256, total_bits=7, seed=23)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    nq, top_k, nprobe, ns = 512, 10, 32, 3
+    q = make_dataset(nq, 960, 64, 24)
+    rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, top_k, nprobe)
+    assert rc == 0
+    qd = torch.from_numpy(q).to(dev)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(ns - 1)]
+    d_ids = [torch.zeros(nq, top_k, dtype=torch.int64, device=dev) for _ in range(ns)]
+    d_sc = [torch.zeros(nq, top_k, dtype=torch.float32, device=dev) for _ in range(ns)]
+    d_cnt = [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(ns)]
+    for rep in range(12):
+        for i in range(ns):
+            idx.search_batch_device(qd.data_ptr(), nq, 960, top_k, nprobe, d_ids[i].data_ptr(), d_sc[i].data_ptr(),
+                                    d_cnt[i].data_ptr(), stream=streams[i].cuda_stream)
+        torch.cuda.synchronize(dev)
+        for i in range(ns):
+            got = d_ids[i].cpu().numpy().view(np.uint64)
+            bad = np.nonzero((got != oids).any(axis=1))[0]
+            assert bad.size == 0, f"rep {rep} stream {i}: ids differ for queries {bad[:10]}"
+            assert np.array_equal(d_cnt[i].cpu().numpy().view(np.uint32), ocnt)
+            d_ids[i].zero_()
     idx.close()
