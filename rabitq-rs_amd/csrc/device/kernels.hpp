@@ -77,6 +77,35 @@ __device__ __forceinline__ float key_to_float(int32_t k) {
 }
 __device__ __forceinline__ bool finite_f(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
 
+// Exclusive prefix sum of one value per thread over a 256-thread workgroup (s_w: 4 words of LDS scratch, free
+// again on return); `total` receives the sum of all values.
+__device__ __forceinline__ uint32_t block_scan_excl256(uint32_t v, uint32_t* s_w, uint32_t tid, uint32_t& total) {
+    static_assert(kThreads == 256, "four waves");
+    const uint32_t lane = tid & 63u;
+    // wave-inclusive scan on DPP: Hillis-Steele inside each row of 16 lanes (row_shr:1,2,4,8, missing lanes read
+    // 0), then lane 15 of row 0/2 into rows 1/3 (row_bcast:15) and lane 31 into rows 2,3 (row_bcast:31)
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    const uint32_t incl = (uint32_t)x;
+    if (lane == 63u) s_w[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t x = s_w[j];
+        off += (uint32_t)j < (tid >> 6) ? x : 0u;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return off + incl - v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_prep: one workgroup per query.
 // ---------------------------------------------------------------------------------------------
@@ -126,6 +155,9 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
     __shared__ float s_sum, s_n2;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const float* qin = queries + (size_t)q * dim;
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
 
     if (rotator == 1) { // FhtKacRotator::rotate_into
         for (uint32_t i = tid; i < D; i += kThreads) x[i] = i < dim ? qin[i] : 0.0f;
@@ -191,6 +223,9 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         }
     }
 
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
     // QueryPrecomputed::new — strictly sequential sums (Rust iter().sum() folds from -0.0)
     if (tid == 0) {
         float s = -0.0f;
@@ -211,6 +246,9 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
     }
     __syncthreads();
 
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
     // pack_lut_f32 + QueryLut::new.  D <= 2048 -> at most 2 codebooks per thread.
     const uint32_t ncb = D / 4;
     float l[2][16];
@@ -290,6 +328,9 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         qc.sum_vl = vl * (float)(D / 4);
         qc.qnorm = sqrtf(s_n2);
         qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
+#ifdef RBQ_PREP_STAMPS
+        qc.pad0 = (float)(pt1 - pt0); qc.pad1 = (float)(pt2 - pt1); qc.pad2 = (float)(__builtin_amdgcn_s_memtime() - pt2);
+#endif
         qc.k1x = -0.5f * s_sum;
         const float cb = -((float)(1u << ex_bits) - 0.5f);
         qc.kbx = cb * s_sum;

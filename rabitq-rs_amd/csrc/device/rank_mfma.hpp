@@ -277,7 +277,11 @@ __device__ __forceinline__ float canon_pair2(const float* qrot, const float* __r
     return sum;
 }
 
-// dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when row_in_lds)
+// dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when RM == 1) |
+//              pgeo[4][nprobe] u32 (only when `stage`: g_add, g_err, first block, vector count of every probe)
+// RM: where the query's row of approximate scores lives during the selection passes — 2: in registers (nlist <=
+// 4096, 16 per thread), 1: staged in LDS, 0: re-read from global memory.
+template <int RM>
 __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_t nlist, uint32_t nprobe,
                                                           uint32_t cap2, int row_in_lds, int metric, const float* __restrict__ rot,
                                                           const float* __restrict__ cent, uint32_t D,
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
                                                           unsigned long long* __restrict__ nvec_probed,
                                                           unsigned long long* __restrict__ prof_total,
                                                           unsigned int* __restrict__ fallback_count, int force_fallback,
-                                                          const BlockSummary* __restrict__ bsum) {
+                                                          const BlockSummary* __restrict__ bsum, int stage) {
     extern __shared__ __align__(16) unsigned char smraw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smraw);
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)cap2 * 8);
@@ -297,61 +301,140 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_mask, s_k, s_cnt, s_bad;
     __shared__ unsigned long long s_nvec;
+#ifdef RBQ_SEL_STAMPS
+    unsigned long long ts[8]; int tn = 0;
+#define SSTAMP() ts[tn++] = __builtin_amdgcn_s_memtime()
+#else
+#define SSTAMP()
+#endif
+    SSTAMP();
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     float* grow = approx + (size_t)q * nlist;
-    float* sc = grow;
-    if (row_in_lds) { // the approximate row is read ~6 times: keep it in LDS when it fits
-        float* lrow = reinterpret_cast<float*>(part + kThreads);
-        for (uint32_t i = tid; i < nlist; i += kThreads) lrow[i] = grow[i];
-        sc = lrow;
-    }
-
-    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
-    if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
-    __syncthreads();
-
+    float* lrow = reinterpret_cast<float*>(part + kThreads); // RM == 1
+    uint32_t* pgeo = reinterpret_cast<uint32_t*>(lrow + (RM == 1 ? nlist : 0u)); // `stage`
+    constexpr int KPT = 16;
+    uint32_t kreg[KPT]; // RM == 2: ordered keys of elements (u>>2)*1024 + 4*tid + (u&3)
+    bool bad_load = false;
     // ordered 32-bit key of the approximate score (ascending = better)
     auto okey = [&](float s) -> uint32_t {
         int32_t k = total_key(s);
         if (metric == 1) k = ~k;
         return (uint32_t)k ^ 0x80000000u;
     };
-    // 1. tau = nprobe-th best approximate score (value only: 4 radix passes over the 32-bit key)
+    if (RM == 2) {
+#pragma unroll
+        for (int v = 0; v < KPT / 4; ++v) {
+            const uint32_t i = v * 1024u + tid * 4u;
+            float4 x = make_float4(0, 0, 0, 0);
+            if (i + 3 < nlist) x = *reinterpret_cast<const float4*>(grow + i);
+            else { if (i < nlist) x.x = grow[i]; if (i + 1 < nlist) x.y = grow[i + 1]; if (i + 2 < nlist) x.z = grow[i + 2]; }
+            bad_load |= !finite_f(x.x) || !finite_f(x.y) || !finite_f(x.z) || !finite_f(x.w);
+            kreg[4 * v] = okey(x.x); kreg[4 * v + 1] = okey(x.y); kreg[4 * v + 2] = okey(x.z); kreg[4 * v + 3] = okey(x.w);
+        }
+    } else if (RM == 1) { // the approximate row is read ~6 times: keep it in LDS when it fits
+        for (uint32_t i = tid; i < nlist; i += kThreads) lrow[i] = grow[i];
+    }
+    // body(i, key) for every list of this thread
+    auto each_key = [&](auto&& body) {
+        if (RM == 2) {
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) {
+                const uint32_t i = (uint32_t)(u >> 2) * 1024u + tid * 4u + (uint32_t)(u & 3);
+                if (i < nlist) body(i, kreg[u]);
+            }
+        } else if (RM == 1) {
+            for (uint32_t i = tid; i < nlist; i += kThreads) { const float v = lrow[i]; bad_load |= !finite_f(v); body(i, okey(v)); }
+        } else {
+            for (uint32_t i = tid; i < nlist; i += kThreads) { const float v = grow[i]; bad_load |= !finite_f(v); body(i, okey(v)); }
+        }
+    };
+
+    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
+    if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
+    __syncthreads();
+
+    SSTAMP(); // 1: row + query staged
+    // 1. tau = nprobe-th best approximate score (value only).  Radix select over the RANGE the keys actually
+    // span: every pass spreads the remaining candidates over 256 bins of [lo, hi] (the top byte of an f32 key
+    // is the same for nearly all scores, which would serialise 4096 LDS atomics on one counter), the bin
+    // holding rank k is found with a workgroup prefix sum, and [lo, hi] shrinks to that bin.
     bool all = nprobe >= nlist;
+    __shared__ uint32_t s_lo, s_hi, s_bin, s_cum, s_h, s_ng, s_w4[4];
+    if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0u; s_ng = 0u; }
+    __syncthreads();
+    {
+        uint32_t kmn = 0xffffffffu, kmx = 0u;
+        each_key([&](uint32_t, uint32_t key) {
+            kmn = key < kmn ? key : kmn;
+            kmx = key > kmx ? key : kmx;
+        });
+        const bool bad = bad_load;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint32_t a = __shfl_xor(kmn, d, 64), b = __shfl_xor(kmx, d, 64);
+            kmn = a < kmn ? a : kmn;
+            kmx = b > kmx ? b : kmx;
+        }
+        if ((tid & 63u) == 0) { atomicMin(&s_lo, kmn); atomicMax(&s_hi, kmx); }
+        if (bad) s_bad = 1;
+    }
+    __syncthreads();
+    uint32_t tau_key = 0;
     if (!all) {
-        for (int pass = 3; pass >= 0; --pass) {
-            const int shift = pass * 8;
+        uint32_t lo = s_lo, hi = s_hi, k = nprobe - 1;
+        while (true) {
+            const uint32_t span = hi - lo;
+            const uint32_t sh = span < 256u ? 0u : (32u - (uint32_t)__builtin_clz(span)) - 8u; // span >> sh in [128, 255]
             hist[tid] = 0;
             __syncthreads();
-            const uint32_t prefix = s_prefix, mask = s_mask;
-            for (uint32_t i = tid; i < nlist; i += kThreads) {
-                const float s = sc[i];
-                if (!finite_f(s)) s_bad = 1;
-                const uint32_t key = okey(s);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
+            each_key([&](uint32_t, uint32_t key) {
+                if (key - lo <= hi - lo) atomicAdd(&hist[(key - lo) >> sh], 1u); // lo <= key <= hi
+            });
             __syncthreads();
-            if (tid == 0) {
-                uint32_t k = s_k, cum = 0, b = 0;
-                for (; b < 256; ++b) {
-                    const uint32_t h = hist[b];
-                    if (k < cum + h) break;
-                    cum += h;
+            const uint32_t h = hist[tid];
+            uint32_t total;
+            const uint32_t excl = block_scan_excl256(h, s_w4, tid, total);
+            if (excl <= k && k < excl + h) { s_bin = tid; s_cum = excl; s_h = h; } // exactly one thread
+            __syncthreads();
+            k -= s_cum;
+            lo += s_bin << sh;
+            const uint32_t width = (sh ? (1u << sh) : 1u) - 1u;
+            if (hi - lo > width) hi = lo + width;
+            if (sh == 0) break; // lo is the key of rank nprobe-1
+            const uint32_t nc = s_h;
+            if (nc <= (uint32_t)kThreads) {
+                // few candidates left (the usual case after ONE pass): gather them and take the one of rank k
+                // by counting — 3 barriers instead of 5 per further radix pass
+                uint32_t* cand = hist; // (every thread has read its bin count; this happens at most once)
+                each_key([&](uint32_t, uint32_t key) {
+                    if (key - lo <= hi - lo) cand[atomicAdd(&s_ng, 1u)] = key;
+                });
+                __syncthreads();
+                if (tid < nc) {
+                    const uint32_t my = cand[tid];
+                    uint32_t less = 0, eq = 0;
+                    for (uint32_t j = 0; j < nc; ++j) {
+                        const uint32_t kj = cand[j];
+                        less += kj < my ? 1u : 0u;
+                        eq += kj == my ? 1u : 0u;
+                    }
+                    if (less <= k && k < less + eq) s_lo = my; // every such thread holds the same key
                 }
-                s_k = k - cum;
-                s_prefix = prefix | (b << shift);
-                s_mask = mask | (0xffu << shift);
+                __syncthreads();
+                lo = s_lo;
+                break;
             }
-            __syncthreads();
         }
+        tau_key = lo;
     }
+    SSTAMP(); // 2: radix select done
     // 2. shortlist: approximate score within 2*eps of tau
     const QueryConsts qc = consts[q];
     const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + cnorm2_max) * 1.001f;
     uint32_t cut = 0xffffffffu;
     if (!all) {
         // back from ordered key to the score value
-        int32_t k = (int32_t)(s_prefix ^ 0x80000000u);
+        int32_t k = (int32_t)(tau_key ^ 0x80000000u);
         if (metric == 1) k = ~k;
         const float tau = key_to_float(k);
         const float lim = metric == 0 ? tau + 2.0f * eps : tau - 2.0f * eps;
@@ -362,16 +445,17 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     __syncthreads();
     bool fallback = s_bad != 0 || force_fallback != 0;
     if (!fallback) {
-        for (uint32_t i = tid; i < nlist; i += kThreads) {
-            if (okey(sc[i]) <= cut) {
+        each_key([&](uint32_t i, uint32_t key) {
+            if (key <= cut) {
                 const uint32_t p = atomicAdd(&s_cnt, 1u);
                 if (p < cap2) keys[p] = i; // cid for now; exact key after the canonical pass
             }
-        }
+        });
         __syncthreads();
         fallback = s_cnt > cap2 || s_cnt < nprobe;
     }
     __syncthreads();
+    SSTAMP(); // 3: shortlist collected
     const uint32_t l2 = tid & 1u, grp = tid >> 1; // 128 pairs in flight
     if (!fallback) {
         // 3. exact canonical scores of the shortlist, exact (score, cid) keys, sort
@@ -388,6 +472,24 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
             if (i < n && l2 == 0) keys[i] = make_key(s, cid, metric);
         }
         __syncthreads();
+        SSTAMP(); // 4: canonical scores
+        if (cap2 <= 2 * kThreads) {
+            // rank sort: the keys are distinct (they carry the list id), so the number of smaller keys IS the
+            // position; every thread walks the n keys as LDS broadcasts — no barrier per compare-exchange stage
+            uint64_t my[2] = {~0ull, ~0ull};
+            uint32_t rk[2] = {0, 0};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) my[u] = keys[tid + u * kThreads];
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint64_t kj = keys[j];
+                rk[0] += kj < my[0] ? 1u : 0u;
+                rk[1] += kj < my[1] ? 1u : 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) keys[rk[u]] = my[u];
+            __syncthreads();
+        } else
         for (uint32_t k = 2; k <= cap2; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 for (uint32_t i = tid; i < cap2; i += kThreads) {
@@ -468,6 +570,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
             }
     }
 
+    SSTAMP(); // 5: sorted
     // 4. per-probe constants (src/ivf.rs:1850-1857), block counts, work list — as k_select.
     // IP needs the canonical centroid distance of every probed list as well (g_error): computed by the same
     // 2-lane groups, 128 lists per round, and parked in the (now free) tail of the key buffer.
@@ -485,13 +588,9 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
         }
         __syncthreads();
     }
-    const uint32_t per = (nprobe + kThreads - 1) / kThreads;
-    const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
-    uint32_t local = 0;
-    unsigned long long local_vec = 0;
-    for (uint32_t r = r0; r < r1; ++r) {
+    // per-probe constants from the sorted key (the same operations wherever they are needed)
+    auto probe_consts = [&](uint32_t r) -> ProbeInfo {
         const uint64_t key = keys[r];
-        const uint32_t cid = (uint32_t)(key & 0xffffffffu);
         int32_t k = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
         if (metric == 1) k = ~k;
         const float s = key_to_float(k);
@@ -504,38 +603,102 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
         pi.g_add = metric == 0 ? dist : -dot;
         pi.g_err = sqrtf(dist);
         pi.dotqc = dot;
-        pi.cid = cid;
+        pi.cid = (uint32_t)(key & 0xffffffffu);
+        return pi;
+    };
+    // first stream position of every probe: workgroup prefix sum over the lists' block counts
+    uint32_t* pstart = reinterpret_cast<uint32_t*>(dist_ip + nprobe); // cap2 >= 2*nprobe: room for nprobe words more
+    const uint32_t per = (nprobe + kThreads - 1) / kThreads;
+    const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
+    uint32_t local = 0;
+    unsigned long long local_vec = 0;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const ProbeInfo pi = probe_consts(r);
         probe[(size_t)q * nprobe + r] = pi;
-        local += (list_n[cid] + 31u) >> 5;
-        local_vec += list_n[cid];
+        const uint32_t n = list_n[pi.cid];
+        if (stage) {
+            pgeo[r] = __float_as_uint(pi.g_add);
+            pgeo[nprobe + r] = __float_as_uint(pi.g_err);
+            pgeo[2 * nprobe + r] = list_gb0[pi.cid];
+            pgeo[3 * nprobe + r] = n;
+        }
+        local += (n + 31u) >> 5;
+        local_vec += n;
     }
-    part[tid] = local;
     if (local_vec) atomicAdd(&s_nvec, local_vec);
-    __syncthreads();
+    uint32_t run;
+    uint32_t acc0 = block_scan_excl256(local, s_w4, tid, run);
+    for (uint32_t r = r0; r < r1; ++r) {
+        pstart[r] = acc0;
+        acc0 += ((stage ? pgeo[3 * nprobe + r] : list_n[(uint32_t)(keys[r] & 0xffffffffu)]) + 31u) >> 5;
+    }
     if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < kThreads; ++i) { const uint32_t v = part[i]; part[i] = run; run += v; }
         nstream[q] = run;
         nvec_probed[q] = s_nvec;
         if (prof_total) atomicAdd(prof_total, s_nvec);
     }
     __syncthreads();
-    uint64_t pos = (uint64_t)q * wl_stride + part[tid];
+    // the block stream, four entries per thread and step (their block summaries are all requested before the
+    // first bound is evaluated): probe = last r with pstart[r] <= i
     const QueryConsts qcs = consts[q];
-    for (uint32_t r = r0; r < r1; ++r) {
-        const uint32_t cid = (uint32_t)(keys[r] & 0xffffffffu);
-        const uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
-        const ProbeInfo pi = probe[(size_t)q * nprobe + r]; // written by this thread above
-        for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
-            StreamItem wi;
-            wi.gblock = gb + b;
-            wi.rank_nvalid = (r << 6) | nv;
-            wi.lbmin = block_lbmin(bsum[gb + b], pi.g_add, pi.g_err, qcs);
-            wi.pad = 0;
-            wl[pos++] = wi;
+    StreamItem* out = wl + (size_t)q * wl_stride;
+    for (uint32_t base = 0; base < run; base += 4 * kThreads) {
+        uint32_t rr[4], gbb[4], nvv[4];
+        BlockSummary bs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + u * kThreads + tid;
+            rr[u] = 0; gbb[u] = 0; nvv[u] = 0;
+            if (i < run) {
+                uint32_t lo = 0, hi = nprobe; // pstart[lo] <= i < pstart[hi] (pstart[nprobe] = run)
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pstart[mid] <= i) lo = mid; else hi = mid;
+                }
+                // lists without vectors share their start with the next one: the LAST r with pstart[r] <= i owns i
+                uint32_t n, gb;
+                if (stage) { gb = pgeo[2 * nprobe + lo]; n = pgeo[3 * nprobe + lo]; }
+                else {
+                    const uint32_t cid = (uint32_t)(keys[lo] & 0xffffffffu);
+                    n = list_n[cid]; gb = list_gb0[cid];
+                }
+                const uint32_t nb = (n + 31u) >> 5, b = i - pstart[lo];
+                rr[u] = lo;
+                gbb[u] = gb + b;
+                nvv[u] = (b + 1 == nb) ? n - b * 32u : 32u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bs[u] = bsum[gbb[u]]; // (block 0 for the idle slots)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + u * kThreads + tid;
+            if (i < run) {
+                float g_add, g_err;
+                if (stage) { g_add = __uint_as_float(pgeo[rr[u]]); g_err = __uint_as_float(pgeo[nprobe + rr[u]]); }
+                else { const ProbeInfo pi = probe_consts(rr[u]); g_add = pi.g_add; g_err = pi.g_err; }
+                StreamItem wi;
+                wi.gblock = gbb[u];
+                wi.rank_nvalid = (rr[u] << 6) | nvv[u];
+                wi.lbmin = block_lbmin(bs[u], g_add, g_err, qcs);
+                wi.pad = 0;
+                out[i] = wi;
+            }
         }
     }
+#ifdef RBQ_SEL_STAMPS
+    SSTAMP(); // 6: probe info + stream written
+    if (tid == 0) {
+        unsigned long long pk = 0;
+#if RBQ_SEL_STAMPS == 2
+        pk = ((ts[0] & 0xffffffffull) << 32) | ((ts[6] - ts[0]) & 0xffffffffull); // absolute start | duration
+        nvec_probed[q] = pk;
+#else
+        for (int t = 0; t < 6; ++t) pk |= (((ts[t + 1] - ts[t]) >> 8) & 0x3ffull) << (10 * t); // 256-cycle units, 10 bits each
+        nvec_probed[q] = pk | ((unsigned long long)s_cnt << 60);
+#endif
+    }
+#endif
 }
 
 // MSTG posting-list scan: the caller supplies each query's posting lists; this emits the

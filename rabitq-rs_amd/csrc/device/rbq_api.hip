@@ -512,17 +512,28 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         {
             ProfScope ps(ix, 2, stream); // shortlist + exact canonical scores + exact select
             const uint32_t cap2 = std::max<uint32_t>(64u, next_pow2(2 * nprobe));
-            const int row_in_lds = (size_t)nlist * 4 <= 65536 ? 1 : 0;
-            const size_t lds = (size_t)cap2 * 8 + (size_t)D * 4 + kThreads * 4 + (row_in_lds ? (size_t)nlist * 4 : 0);
-            if (lds > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_select_mfma, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (float*)w->scores.p, nlist, nprobe,
-                               cap2, row_in_lds, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
-                               (const QueryConsts*)w->consts.p, ix->cnorm2_max, (const uint32_t*)ix->d_list_gb0,
-                               (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p, (StreamItem*)w->wl.p, wl_stride,
-                               (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
-                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr, (unsigned int*)ix->d_fallbacks,
-                               ix->force_rank_fallback ? 1 : 0, (const BlockSummary*)ix->d_bsum);
+            const int row_in_lds = (nlist > 4096 && (size_t)nlist * 4 <= 65536) ? 1 : 0; // <= 4096: registers
+            size_t lds = (size_t)cap2 * 8 + (size_t)D * 4 + kThreads * 4 + (row_in_lds ? (size_t)nlist * 4 : 0);
+            const int stage = lds + (size_t)nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
+            if (stage) lds += (size_t)nprobe * 16;
+#define RBQ_LAUNCH_SELECT(RM)                                                                                         \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mfma<RM>),                             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL(k_select_mfma<RM>, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (float*)w->scores.p,    \
+                           nlist, nprobe, cap2, row_in_lds, (int)ix->metric, (const float*)w->rot.p,                   \
+                           (const float*)ix->d_centroids, D, (const QueryConsts*)w->consts.p, ix->cnorm2_max,          \
+                           (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,     \
+                           (StreamItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,   \
+                           ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr,                            \
+                           (unsigned int*)ix->d_fallbacks, ix->force_rank_fallback ? 1 : 0,                            \
+                           (const BlockSummary*)ix->d_bsum, stage);                                                    \
+    } while (0)
+            if (nlist <= 4096) RBQ_LAUNCH_SELECT(2);
+            else if (row_in_lds) RBQ_LAUNCH_SELECT(1);
+            else RBQ_LAUNCH_SELECT(0);
+#undef RBQ_LAUNCH_SELECT
             HIP_TRY(hipGetLastError());
         }
     }
@@ -953,6 +964,7 @@ int rbq_debug_copy_workspace(rbq_index* ix, void* hip_stream, const char* name, 
     else if (!std::strcmp(name, "probe")) b = &w->probe;
     else if (!std::strcmp(name, "nstream")) b = &w->nstream;
     else if (!std::strcmp(name, "wl")) b = &w->wl;
+    else if (!std::strcmp(name, "nvec")) b = &w->nvec;
     if (!b || !b->p || bytes > b->cap) return fail(RBQ_INVALID_CONFIG, "unknown buffer or size");
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));

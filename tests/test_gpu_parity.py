@@ -321,3 +321,22 @@ def test_concurrent_streams_match_oracle():
             assert np.array_equal(d_cnt[i].cpu().numpy().view(np.uint32), ocnt)
             d_ids[i].zero_()
     idx.close()
+
+
+@pytest.mark.parametrize("nlist", [5000, 17000])
+def test_many_lists_select_row_modes(nlist):
+    """nlist > 4096 keeps the approximate score row in LDS, nlist > 16384 re-reads it from global memory
+    (k_select_mfma<1>/<0>); both must select the reference's probes."""
+    import torch
+    dim, n = 64, 3 * nlist
+    data = make_dataset(n, dim, 64, 31)
+    rng = np.random.default_rng(32)
+    cent = data[rng.choice(n, nlist, replace=False)].copy()
+    x, c = torch.from_numpy(data).cuda(), torch.from_numpy(cent).cuda()
+    assign = torch.cdist(x, c).argmin(dim=1).cpu().numpy().astype(np.uint32)
+    built = rq.builder.train_with_clusters(data, cent, assign, 7, 0, 1, 33, True)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(48, dim, 64, 34)
+    _compare(built, idx, q, 10, 40)
+    assert idx.rank_fallbacks() == 0
+    idx.close()

@@ -1,0 +1,38 @@
+"""Diagnostic: per-phase cycles of k_select_mfma from a -DRBQ_SEL_STAMPS build (RBQ_LIB_PATH=.../librbq_sel.so)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench
+import rabitq_rs_amd as rq
+a = bench.parse()
+dev = torch.device("cuda", 0)
+x = bench.mixture(torch, dev, a.n, a.dim, a.nlist, 20260105, False)
+cent, assign = bench.kmeans_gpu(torch, x, a.nlist, 6, 20260103)
+built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits, 0, 1, 20260104, True)
+idx = rq.IvfRabitqIndex.from_built(built)
+qd = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).contiguous()
+s = torch.cuda.Stream(dev)
+o = (torch.zeros(a.batch, a.top_k, dtype=torch.int64, device=dev), torch.zeros(a.batch, a.top_k, dtype=torch.float32, device=dev), torch.zeros(a.batch, dtype=torch.int32, device=dev))
+for _ in range(3):
+    idx.search_batch_device(qd.data_ptr(), a.batch, a.dim, a.top_k, a.nprobe, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), stream=s.cuda_stream)
+torch.cuda.synchronize(dev)
+v = idx.debug_copy_workspace(s.cuda_stream, "nvec", np.empty(a.batch, np.uint64))
+if os.environ.get("SEL_MODE") == "prep":
+    c = idx.debug_copy_workspace(s.cuda_stream, "consts", np.empty(a.batch * 12, np.float32)).reshape(a.batch, 12)
+    print("k_prep ticks: rotate %.0f  sums %.0f  lut+consts %.0f" % (c[:, 7].mean(), c[:, 8].mean(), c[:, 9].mean()))
+    sys.exit(0)
+if os.environ.get("SEL_MODE") == "2":
+    st = (v >> np.uint64(32)).astype(np.int64); du = (v & np.uint64(0xffffffff)).astype(np.int64)
+    st = (st - st.min()) & 0xffffffff
+    print("starts: min 0 p50 %d p90 %d max %d ; duration mean %d p99 %d ; last end %d" % (np.percentile(st, 50), np.percentile(st, 90), st.max(), du.mean(), np.percentile(du, 99), (st + du).max()))
+    order = np.argsort(st)
+    print("start of WG #0,256,512,768,1023 in start order:", st[order][[0, 256, 512, 768, 1023]])
+    sys.exit(0)
+names = ["stage row+q", "radix select", "shortlist", "canonical", "sort", "probe+stream"]
+tot = 0
+for t, n in enumerate(names):
+    c = ((v >> np.uint64(10 * t)) & np.uint64(0x3ff)).astype(np.float64) * 256
+    tot += c.mean()
+    print("%-14s mean %7.0f cycles  p99 %7.0f" % (n, c.mean(), np.percentile(c, 99)))
+print("total %.0f cycles; shortlist size mean (mod 16) %.1f" % (tot, (v >> np.uint64(60)).astype(np.float64).mean()))
