@@ -99,6 +99,20 @@ int rbq_index_create(const rbq_header* hdr, const rbq_list_view* lists,
 int rbq_index_load_rbq1(const void* bytes, size_t len,
                         int n_devices, const int* devices, rbq_index** out);
 
+/* GPU-side encoder: build the index on the device from raw vectors — the quantisation loop of
+ * `IvfRabitqIndex::train_with_clusters` / `build_from_rotated` (src/ivf.rs:1025-1215: rotate, group by cluster in
+ * ascending vector order, `quantize_with_centroid` src/quantizer.rs:140-262 with the constant rescale factor of
+ * `RabitqConfig::faster`, src/quantizer.rs:33-46,563-592) — writing the device layout directly.  Clustering stays
+ * with the caller (the reference accepts any clustering here).
+ *   hdr        dim, padded_dim, metric, rotator (+ rotator_blob/len), ex_bits, n_lists; n_vectors is ignored
+ *   centroids  HOST  [n_lists][dim]  cluster centroids in the input space
+ *   d_data     DEVICE [n][dim]       vectors; the id of vector i is i
+ *   d_assign   DEVICE [n]            cluster of every vector (< n_lists, else RBQ_INVALID_CONFIG)
+ *   t_const    the constant scaling factor (`compute_const_scaling_factor`); required when ex_bits > 0
+ * The result is identical, array for array, to rbq_index_create over the CPU path's ClusterData. */
+int rbq_index_build_device(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
+                           uint64_t n, float t_const, int device, rbq_index** out);
+
 void rbq_index_destroy(rbq_index* idx);
 
 /* Accessors (IvfRabitqIndex::len / cluster_count, src/ivf.rs:1218-1230). */
@@ -170,6 +184,9 @@ uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
  * re-run inside the scan kernel with the exact BinaryHeap emulation (src/ivf.rs:2078-2105 pushes into a
  * std BinaryHeap, whose tie behaviour depends on its layout). Diagnostic. */
 uint64_t rbq_debug_heap_restarts(const rbq_index* idx);
+/* Diagnostic: copy one of the index's device arrays ("blocks", "ids", "ex", "fadd_ex", "fres_ex", "bsum",
+ * "centroids", "list_gb0", "list_n") to the host; `bytes` must be the array's exact size. */
+int rbq_debug_copy_index(rbq_index* idx, const char* name, void* dst, uint64_t bytes);
 /* Diagnostic: copy an intermediate buffer ("rot", "lut", "consts", "scores", "probe", "nstream", "wl") of the
  * workspace that rbq_search_batch_device bound to `hip_stream`; the caller has synchronised that stream. */
 int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name, void* dst, uint64_t bytes);

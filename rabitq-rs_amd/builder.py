@@ -62,6 +62,15 @@ class BuiltIndex:
         return self.hdr_ptr.contents
 
     @property
+    def hdr(self):
+        return self.hdr_ptr.contents
+
+    @property
+    def t_const(self):
+        """Constant rescale factor of the faster config (0.0 when it was not used)."""
+        return float(lib().rbq_built_t_const(self._h))
+
+    @property
     def dim(self):
         return self.header.dim
 

@@ -141,24 +141,12 @@ __host__ __device__ inline void bf16_split(float x, uint16_t& hi, uint16_t& lo) 
     lo = bf16_rne(x - bf16_to_f32(hi));
 }
 
-__global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ queries, uint32_t dim, uint32_t D,
-                                                   uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
-                                                   uint32_t trunc, float fac, uint32_t ex_bits,
-                                                   float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
-                                                   QueryConsts* __restrict__ consts,
-                                                   uint16_t* __restrict__ rot_hi, uint16_t* __restrict__ rot_lo) {
-    extern __shared__ __align__(16) float sm[];
-    float* x = sm;         // [D]
-    float* y = sm + D;     // [D] (matrix rotator input)
-    __shared__ int s_kmin, s_kmax;
-    __shared__ unsigned int s_amin, s_amax;
-    __shared__ float s_sum, s_n2;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const float* qin = queries + (size_t)q * dim;
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
-#endif
-
+// Rotator::rotate_into for one vector, by one 256-thread workgroup: the rotated vector ends up in x[0..D)
+// (LDS); y[0..D) is scratch for the matrix rotator.  Butterflies/adds are the reference's, stage by stage
+// (src/rotation.rs:248-401), so the result is bit-identical to the CPU path.
+__device__ __forceinline__ void rotate_into_lds(float* x, float* y, const float* __restrict__ qin, uint32_t dim, uint32_t D,
+                                                int rotator, const uint8_t* __restrict__ rot_blob, uint32_t trunc,
+                                                float fac, uint32_t tid) {
     if (rotator == 1) { // FhtKacRotator::rotate_into
         for (uint32_t i = tid; i < D; i += kThreads) x[i] = i < dim ? qin[i] : 0.0f;
         __syncthreads();
@@ -212,6 +200,28 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         }
         __syncthreads();
     }
+
+}
+
+__global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ queries, uint32_t dim, uint32_t D,
+                                                   uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
+                                                   uint32_t trunc, float fac, uint32_t ex_bits,
+                                                   float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
+                                                   QueryConsts* __restrict__ consts,
+                                                   uint16_t* __restrict__ rot_hi, uint16_t* __restrict__ rot_lo) {
+    extern __shared__ __align__(16) float sm[];
+    float* x = sm;         // [D]
+    float* y = sm + D;     // [D] (matrix rotator input)
+    __shared__ int s_kmin, s_kmax;
+    __shared__ unsigned int s_amin, s_amax;
+    __shared__ float s_sum, s_n2;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const float* qin = queries + (size_t)q * dim;
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
+
+    rotate_into_lds(x, y, qin, dim, D, rotator, rot_blob, trunc, fac, tid);
 
     for (uint32_t i = tid; i < D; i += kThreads) {
         rot_out[(size_t)q * D + i] = x[i];

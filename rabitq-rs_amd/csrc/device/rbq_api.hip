@@ -20,6 +20,8 @@
 #include "kernels.hpp"
 #include "scan.hpp"
 #include "rank_mfma.hpp"
+#include "encode.hpp"
+#include <rocprim/rocprim.hpp>
 
 using namespace rbq;
 
@@ -210,6 +212,35 @@ int upload(void** dptr, const std::vector<T>& v) {
     return RBQ_OK;
 }
 
+// arrays derived from the rotated centroids + the diagnostic counters (shared by create_impl and the device build)
+int finish_centroid_arrays(rbq_index* ix, const std::vector<float>& cent) {
+    const uint32_t D = ix->D;
+    std::vector<float> cn(ix->n_lists);
+    double mx = 0;
+    for (uint64_t c = 0; c < ix->n_lists; ++c) {
+        double a = 0;
+        for (uint32_t i = 0; i < D; ++i) a += (double)cent[c * D + i] * (double)cent[c * D + i];
+        cn[c] = (float)a;
+        if (std::isfinite(a)) mx = std::max(mx, a);
+    }
+    ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
+    int rc;
+    if ((rc = upload(&ix->d_cnorm2, cn))) return rc;
+    std::vector<uint16_t> ch(cent.size()), cl(cent.size()); // split-bf16 image of the centroids (k_rank_bf16)
+    for (size_t i = 0; i < cent.size(); ++i) bf16_split(cent[i], ch[i], cl[i]);
+    if ((rc = upload(&ix->d_cent_hi, ch))) return rc;
+    if ((rc = upload(&ix->d_cent_lo, cl))) return rc;
+    std::vector<unsigned int> z(2, 0); // [0] rank fallbacks, [1] heap restarts
+    if ((rc = upload(&ix->d_fallbacks, z))) return rc;
+    std::vector<unsigned long long> z1(1, 0);
+    if ((rc = upload(&ix->d_prof_total, z1))) return rc;
+    const char* e = std::getenv("RBQ_EXACT_RANK");
+    ix->exact_rank = e && e[0] == '1';
+    const char* f = std::getenv("RBQ_FORCE_RANK_FALLBACK");
+    ix->force_rank_fallback = f && f[0] == '1';
+    return RBQ_OK;
+}
+
 int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices, const int* devices, rbq_index** out) {
     if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
     *out = nullptr;
@@ -307,30 +338,168 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     } while (0)
     UP(d_rot_blob, blob); UP(d_centroids, cent); UP(d_blocks, blocks); UP(d_ids, ids); UP(d_ex, ex);
     UP(d_fadd_ex, fa); UP(d_fres_ex, fr); UP(d_list_gb0, gb0); UP(d_list_n, ln);
-    { std::vector<unsigned long long> z(1, 0); UP(d_prof_total, z); }
     UP(d_bsum, bsum);
-    {
-        std::vector<float> cn(ix->n_lists);
-        double mx = 0;
-        for (uint64_t c = 0; c < ix->n_lists; ++c) {
-            double a = 0;
-            for (uint32_t i = 0; i < D; ++i) a += (double)cent[c * D + i] * (double)cent[c * D + i];
-            cn[c] = (float)a;
-            if (std::isfinite(a)) mx = std::max(mx, a);
-        }
-        ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
-        UP(d_cnorm2, cn);
-        std::vector<uint16_t> ch(cent.size()), cl(cent.size()); // split-bf16 image of the centroids (k_rank_bf16)
-        for (size_t i = 0; i < cent.size(); ++i) bf16_split(cent[i], ch[i], cl[i]);
-        UP(d_cent_hi, ch); UP(d_cent_lo, cl);
-        std::vector<unsigned int> z(2, 0); // [0] rank fallbacks, [1] heap restarts
-        UP(d_fallbacks, z);
-        const char* e = std::getenv("RBQ_EXACT_RANK");
-        ix->exact_rank = e && e[0] == '1';
-        const char* f = std::getenv("RBQ_FORCE_RANK_FALLBACK");
-        ix->force_rank_fallback = f && f[0] == '1';
-    }
+    if ((rc = finish_centroid_arrays(ix, cent))) { free_index(ix); return rc; }
 #undef UP
+    *out = ix;
+    return RBQ_OK;
+}
+
+// ---- GPU-side encoder (encode.hpp): the device analogue of train_with_clusters' quantisation loop ------------
+int build_device_impl(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
+                      uint64_t n, float t_const, int dev, rbq_index** out) {
+    if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
+    *out = nullptr;
+    int rc = validate_header(hdr);
+    if (rc) return rc;
+    if (!centroids || !d_data || !d_assign) return fail(RBQ_INVALID_CONFIG, "null buffer");
+    if (n == 0) return fail(RBQ_INVALID_CONFIG, "no vectors");
+    if (n > 0xfffffff0ull) return fail(RBQ_INVALID_CONFIG, "too many vectors for 32-bit slots");
+    if (hdr->ex_bits > 0 && !(t_const > 0.0f)) return fail(RBQ_INVALID_CONFIG, "the device encoder needs the constant rescale factor (faster config)");
+    HIP_TRY(hipSetDevice(dev));
+
+    rbq_index* ix = new rbq_index();
+    ix->device = dev;
+    ix->dim = hdr->dim; ix->D = hdr->padded_dim; ix->Dc = (hdr->padded_dim + 63u) / 64u * 64u;
+    ix->metric = hdr->metric; ix->rotator = hdr->rotator; ix->ex_bits = hdr->ex_bits;
+    ix->n_lists = hdr->n_lists;
+    ix->trunc = 1u << floor_log2_u32(hdr->dim);
+    ix->fac = 1.0f / std::sqrt((float)ix->trunc);
+    const uint32_t D = ix->D, Dc = ix->Dc, dim = ix->dim, nlist = (uint32_t)ix->n_lists;
+    const size_t dev_stride = (size_t)Dc * 4 + 384, exd = ex_bytes_dev(D, ix->ex_bits);
+
+    std::vector<void*> temps;
+    auto cleanup = [&](int code) { for (void* p : temps) if (p) (void)hipFree(p); if (code) free_index(ix); return code; };
+#define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)fail(RBQ_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); return cleanup(RBQ_DEVICE); } } while (0)
+    auto tmp_alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) temps.push_back(*p); return e; };
+
+    std::vector<uint8_t> blob;
+    if (hdr->rotator_len) blob.assign(hdr->rotator_blob, hdr->rotator_blob + hdr->rotator_len);
+    if ((rc = upload(&ix->d_rot_blob, blob))) return cleanup(rc);
+
+    // rotated centroids
+    std::vector<float> cent((size_t)nlist * D);
+    {
+        float* d_craw = nullptr;
+        TRY(tmp_alloc((void**)&d_craw, (size_t)nlist * dim * 4));
+        TRY(hipMemcpy(d_craw, centroids, (size_t)nlist * dim * 4, hipMemcpyHostToDevice));
+        TRY(hipMalloc(&ix->d_centroids, (size_t)nlist * D * 4));
+        hipLaunchKernelGGL(k_rotate_rows, dim3(nlist), dim3(kThreads), (size_t)D * 4 * 2, 0, (const float*)d_craw, (const uint32_t*)nullptr,
+                           dim, D, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (float*)ix->d_centroids);
+        TRY(hipGetLastError());
+        TRY(hipMemcpy(cent.data(), ix->d_centroids, cent.size() * 4, hipMemcpyDeviceToHost));
+    }
+
+    // list sizes
+    std::vector<uint32_t> ln(nlist), gb0(nlist);
+    {
+        uint32_t* d_counts = nullptr;
+        TRY(tmp_alloc((void**)&d_counts, (size_t)(nlist + 1) * 4));
+        TRY(hipMemset(d_counts, 0, (size_t)(nlist + 1) * 4));
+        hipLaunchKernelGGL(k_count_assign, dim3(1024), dim3(256), 0, 0, d_assign, n, nlist, d_counts, d_counts + nlist);
+        TRY(hipGetLastError());
+        std::vector<uint32_t> hc(nlist + 1);
+        TRY(hipMemcpy(hc.data(), d_counts, hc.size() * 4, hipMemcpyDeviceToHost));
+        if (hc[nlist]) { (void)fail(RBQ_INVALID_CONFIG, "assignment out of range"); return cleanup(RBQ_INVALID_CONFIG); }
+        std::copy(hc.begin(), hc.begin() + nlist, ln.begin());
+    }
+    uint64_t nblocks = 0;
+    std::vector<uint64_t> vstart(nlist);
+    {
+        uint64_t run = 0;
+        for (uint32_t c = 0; c < nlist; ++c) { gb0[c] = (uint32_t)nblocks; vstart[c] = run; nblocks += (ln[c] + 31u) / 32u; run += ln[c]; }
+    }
+    if (nblocks * 32 > 0xffffffffull) { (void)fail(RBQ_INVALID_CONFIG, "index too large for 32-bit vector slots"); return cleanup(RBQ_INVALID_CONFIG); }
+    ix->n_blocks = nblocks; ix->n_vectors = n; ix->h_list_n = ln;
+    {
+        std::vector<uint64_t> nblk(nlist);
+        for (uint32_t c = 0; c < nlist; ++c) nblk[c] = (ln[c] + 31u) / 32u;
+        std::sort(nblk.begin(), nblk.end(), std::greater<uint64_t>());
+        ix->nblk_desc_prefix.assign(nlist + 1, 0);
+        for (uint32_t c = 0; c < nlist; ++c) ix->nblk_desc_prefix[c + 1] = ix->nblk_desc_prefix[c] + nblk[c];
+    }
+    if ((rc = upload(&ix->d_list_gb0, gb0))) return cleanup(rc);
+    if ((rc = upload(&ix->d_list_n, ln))) return cleanup(rc);
+    const uint64_t nslots = nblocks * 32;
+
+    // stable grouping by list (ascending vector index inside a list, src/ivf.rs:1141-1149): radix sort on the list id
+    uint32_t* d_slot_src = nullptr;
+    {
+        uint32_t *d_ko = nullptr, *d_vi = nullptr, *d_vo = nullptr;
+        uint64_t* d_vstart = nullptr;
+        TRY(tmp_alloc((void**)&d_ko, n * 4)); TRY(tmp_alloc((void**)&d_vi, n * 4)); TRY(tmp_alloc((void**)&d_vo, n * 4));
+        TRY(tmp_alloc((void**)&d_vstart, (size_t)nlist * 8));
+        TRY(hipMemcpy(d_vstart, vstart.data(), (size_t)nlist * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, 0, d_vi, n);
+        TRY(hipGetLastError());
+        unsigned bits = 1;
+        while ((1ull << bits) < nlist) ++bits;
+        size_t tb = 0;
+        TRY(rocprim::radix_sort_pairs(nullptr, tb, d_assign, d_ko, d_vi, d_vo, (size_t)n, 0u, bits, (hipStream_t)0));
+        void* d_tmp = nullptr;
+        TRY(tmp_alloc(&d_tmp, tb));
+        TRY(rocprim::radix_sort_pairs(d_tmp, tb, d_assign, d_ko, d_vi, d_vo, (size_t)n, 0u, bits, (hipStream_t)0));
+        TRY(tmp_alloc((void**)&d_slot_src, nslots * 4));
+        TRY(hipMemset(d_slot_src, 0xff, nslots * 4));
+        hipLaunchKernelGGL(k_scatter_slots, dim3(1024), dim3(256), 0, 0, (const uint32_t*)d_ko, (const uint32_t*)d_vo, n,
+                           (const uint32_t*)ix->d_list_gb0, (const uint64_t*)d_vstart, d_slot_src);
+        TRY(hipGetLastError());
+    }
+    // block -> list, block -> number of real vectors
+    uint32_t *d_block_list = nullptr, *d_block_nv = nullptr;
+    {
+        std::vector<uint32_t> bl(nblocks), bn(nblocks);
+        for (uint32_t c = 0; c < nlist; ++c) {
+            const uint32_t nb = (ln[c] + 31u) / 32u;
+            for (uint32_t b = 0; b < nb; ++b) { bl[gb0[c] + b] = c; bn[gb0[c] + b] = std::min<uint32_t>(32u, ln[c] - b * 32u); }
+        }
+        TRY(tmp_alloc((void**)&d_block_list, nblocks * 4)); TRY(tmp_alloc((void**)&d_block_nv, nblocks * 4));
+        TRY(hipMemcpy(d_block_list, bl.data(), nblocks * 4, hipMemcpyHostToDevice));
+        TRY(hipMemcpy(d_block_nv, bn.data(), nblocks * 4, hipMemcpyHostToDevice));
+    }
+
+    // final arrays
+    TRY(hipMalloc(&ix->d_blocks, nblocks * dev_stride)); TRY(hipMemset(ix->d_blocks, 0, nblocks * dev_stride));
+    TRY(hipMalloc(&ix->d_ids, nslots * 8));
+    TRY(hipMalloc(&ix->d_ex, exd ? nslots * exd + 256 : 16));
+    TRY(hipMalloc(&ix->d_fadd_ex, ix->ex_bits ? nslots * 4 : 16)); TRY(hipMalloc(&ix->d_fres_ex, ix->ex_bits ? nslots * 4 : 16));
+    TRY(hipMalloc(&ix->d_bsum, nblocks * sizeof(BlockSummary)));
+
+    // encode, a chunk of blocks at a time (scratch: rotated rows + raw ex codes of the chunk)
+    {
+        uint64_t chunk_blocks = std::max<uint64_t>(2, ((512ull << 20) / ((size_t)D * 4) / 32) & ~1ull);
+        chunk_blocks = std::min<uint64_t>(chunk_blocks, (nblocks + 1) & ~1ull);
+        const uint64_t chunk_slots = chunk_blocks * 32;
+        float* d_rows = nullptr;
+        uint8_t* d_raw = nullptr;
+        TRY(tmp_alloc((void**)&d_rows, chunk_slots * D * 4));
+        TRY(tmp_alloc((void**)&d_raw, ix->ex_bits ? chunk_slots * D : 16));
+        for (uint64_t b0 = 0; b0 < nblocks; b0 += chunk_blocks) {
+            const uint64_t nb = std::min<uint64_t>(chunk_blocks, nblocks - b0), ns = nb * 32, s0 = b0 * 32;
+            hipLaunchKernelGGL(k_rotate_rows, dim3((uint32_t)ns), dim3(kThreads), (size_t)D * 4 * 2, 0, d_data, (const uint32_t*)(d_slot_src + s0),
+                               dim, D, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, d_rows);
+            TRY(hipGetLastError());
+            EncodeParams P;
+            P.rows = d_rows; P.centroids = (const float*)ix->d_centroids; P.slot_src = d_slot_src + s0; P.block_list = d_block_list + b0;
+            P.blocks = (uint8_t*)ix->d_blocks + b0 * dev_stride; P.raw_ex = d_raw;
+            P.f_add_ex = (float*)ix->d_fadd_ex + s0; P.f_rescale_ex = (float*)ix->d_fres_ex + s0; P.ids = (uint64_t*)ix->d_ids + s0;
+            P.src_base = 0; P.nslots = (uint32_t)ns; P.D = D; P.Dc = Dc; P.ex_bits = ix->ex_bits; P.metric = ix->metric; P.t_const = t_const;
+            hipLaunchKernelGGL(k_encode, dim3((uint32_t)((ns + kEncThreads - 1) / kEncThreads)), dim3(kEncThreads), 0, 0, P);
+            TRY(hipGetLastError());
+            if (ix->ex_bits) {
+                hipLaunchKernelGGL(k_pack_ex, dim3((uint32_t)((ns + 15) / 16)), dim3(256), 0, 0, (const uint8_t*)d_raw, (const uint32_t*)(d_slot_src + s0),
+                                   (uint32_t)ns, D, (uint32_t)ix->ex_bits, (uint8_t*)ix->d_ex + s0 * exd);
+                TRY(hipGetLastError());
+            }
+        }
+        hipLaunchKernelGGL(k_block_summary, dim3((uint32_t)((nblocks + 7) / 8)), dim3(256), 0, 0, (const uint8_t*)ix->d_blocks,
+                           (const uint32_t*)d_block_nv, (uint32_t)nblocks, Dc, (BlockSummary*)ix->d_bsum);
+        TRY(hipGetLastError());
+        TRY(hipDeviceSynchronize());
+    }
+#undef TRY
+    if ((rc = finish_centroid_arrays(ix, cent))) return cleanup(rc);
+    cleanup(0);
     *out = ix;
     return RBQ_OK;
 }
@@ -968,6 +1137,33 @@ int rbq_debug_copy_workspace(rbq_index* ix, void* hip_stream, const char* name, 
     if (!b || !b->p || bytes > b->cap) return fail(RBQ_INVALID_CONFIG, "unknown buffer or size");
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));
+    return RBQ_OK;
+}
+
+int rbq_index_build_device(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
+                           uint64_t n, float t_const, int device, rbq_index** out) {
+    g_err.clear();
+    return build_device_impl(hdr, centroids, d_data, d_assign, n, t_const, device, out);
+}
+
+/* Diagnostic: copy one of the index's device arrays to the host. */
+int rbq_debug_copy_index(rbq_index* ix, const char* name, void* dst, uint64_t bytes) {
+    if (!ix || !name || !dst) return RBQ_INVALID_CONFIG;
+    const size_t stride = (size_t)ix->Dc * 4 + 384, exd = ex_bytes_dev(ix->D, ix->ex_bits), slots = ix->n_blocks * 32;
+    const void* p = nullptr;
+    size_t have = 0;
+    if (!std::strcmp(name, "blocks")) { p = ix->d_blocks; have = ix->n_blocks * stride; }
+    else if (!std::strcmp(name, "ids")) { p = ix->d_ids; have = slots * 8; }
+    else if (!std::strcmp(name, "ex")) { p = ix->d_ex; have = slots * exd; }
+    else if (!std::strcmp(name, "fadd_ex")) { p = ix->d_fadd_ex; have = ix->ex_bits ? slots * 4 : 0; }
+    else if (!std::strcmp(name, "fres_ex")) { p = ix->d_fres_ex; have = ix->ex_bits ? slots * 4 : 0; }
+    else if (!std::strcmp(name, "bsum")) { p = ix->d_bsum; have = ix->n_blocks * sizeof(BlockSummary); }
+    else if (!std::strcmp(name, "centroids")) { p = ix->d_centroids; have = ix->n_lists * ix->D * 4; }
+    else if (!std::strcmp(name, "list_gb0")) { p = ix->d_list_gb0; have = ix->n_lists * 4; }
+    else if (!std::strcmp(name, "list_n")) { p = ix->d_list_n; have = ix->n_lists * 4; }
+    if (!p || bytes != have) return fail(RBQ_INVALID_CONFIG, "unknown array or size (have " + std::to_string(have) + " bytes)");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
     return RBQ_OK;
 }
 

@@ -48,6 +48,10 @@ def lib():
         L.rbq_profile_scan_bytes.argtypes = [vp]
         L.rbq_debug_rank_fallbacks.restype = C.c_uint64
         L.rbq_debug_rank_fallbacks.argtypes = [vp]
+        L.rbq_index_build_device.restype = C.c_int
+        L.rbq_index_build_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_int, vp]
+        L.rbq_debug_copy_index.restype = C.c_int
+        L.rbq_debug_copy_index.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
         L.rbq_debug_copy_workspace.restype = C.c_int
         L.rbq_debug_copy_workspace.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint64]
         L.rbq_debug_heap_restarts.restype = C.c_uint64
@@ -93,6 +97,22 @@ class IvfRabitqIndex:
         dev = (C.c_int * 1)(device) if device is not None else None
         _check(lib().rbq_index_create(_addr(built.hdr_ptr), _addr(built.lists_ptr), 1, dev, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def build_on_device(cls, hdr_ptr, centroids, d_data, d_assign, n, t_const, device=0):
+        """GPU-side encoder (rbq_index_build_device): `hdr_ptr` is a ctypes pointer to an rbq_header (dim,
+        padded_dim, metric, rotator + blob, ex_bits, n_lists), `centroids` a host [n_lists][dim] f32 array,
+        `d_data` / `d_assign` device pointers to [n][dim] f32 vectors and [n] u32 cluster ids."""
+        cent = np.ascontiguousarray(centroids, dtype=np.float32)
+        h = C.c_void_p()
+        _check(lib().rbq_index_build_device(_addr(hdr_ptr), cent.ctypes.data, C.c_void_p(d_data), C.c_void_p(d_assign),
+                                            int(n), float(t_const), int(device), C.byref(h)))
+        return cls(h)
+
+    def debug_copy_index(self, name, out):
+        """Diagnostic: copy one of the index's device arrays into the numpy array `out` (exact size)."""
+        _check(lib().rbq_debug_copy_index(self._h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
 
     @classmethod
     def load_from_bytes(cls, data, device=None):

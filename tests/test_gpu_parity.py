@@ -340,3 +340,49 @@ def test_many_lists_select_row_modes(nlist):
     _compare(built, idx, q, 10, 40)
     assert idx.rank_fallbacks() == 0
     idx.close()
+
+
+ENC_CASES = [
+    # n, dim, nlist, bits, metric, rotator
+    pytest.param(6000, 960, 40, 7, 0, 1, id="enc_d960_7bit_L2"),
+    pytest.param(5000, 960, 40, 3, 1, 1, id="enc_d960_3bit_IP"),
+    pytest.param(4000, 100, 24, 7, 0, 1, id="enc_d100_pad128_7bit_L2"),
+    pytest.param(4000, 128, 32, 1, 0, 1, id="enc_d128_1bit_L2"),
+    pytest.param(3000, 48, 24, 3, 0, 0, id="enc_matrix_d48_3bit_L2"),
+    pytest.param(3000, 64, 20, 7, 1, 0, id="enc_matrix_d64_7bit_IP"),
+]
+
+
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,rot", ENC_CASES)
+def test_device_encoder_matches_cpu_builder(n, dim, nlist, bits, metric, rot):
+    """rbq_index_build_device (GPU quantize_with_centroid, faster config) produces, array for array, the index
+    that rbq_index_create builds from the CPU builder's ClusterData — codes, ex codes, factors, ids, block
+    summaries — and therefore the same search results."""
+    import torch
+    data = make_dataset(n, dim, max(nlist // 4, 1), 41, normalize=(metric == 1))
+    cent, assign = rq.builder.kmeans(data, nlist, 5, 42)
+    built = rq.builder.train_with_clusters(data, cent, assign, bits, metric, rot, 43, True)
+    ref = rq.IvfRabitqIndex.from_built(built)
+    xd = torch.from_numpy(data).cuda()
+    ad = torch.from_numpy(assign.astype(np.int32)).cuda()
+    enc = rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ad.data_ptr(), n, built.t_const)
+    hdr = built.hdr
+    D, ex = hdr.padded_dim, hdr.ex_bits
+    Dc = (D + 63) // 64 * 64
+    gb0 = ref.debug_copy_index("list_gb0", np.empty(nlist, np.uint32))
+    ln = ref.debug_copy_index("list_n", np.empty(nlist, np.uint32))
+    nblocks = int(((ln + 31) // 32).sum())
+    cpu_u = 128 // ex if ex else 1
+    w4 = ((D // 16 + cpu_u - 1) // cpu_u) if ex else 0
+    sizes = {"list_gb0": nlist * 4, "list_n": nlist * 4, "centroids": nlist * D * 4, "blocks": nblocks * (Dc * 4 + 384),
+             "ids": nblocks * 32 * 8, "bsum": nblocks * 32}
+    if ex:
+        sizes.update({"ex": nblocks * 32 * w4 * 256, "fadd_ex": nblocks * 32 * 4, "fres_ex": nblocks * 32 * 4})
+    for name, nbytes in sizes.items():
+        a = ref.debug_copy_index(name, np.empty(nbytes, np.uint8))
+        b = enc.debug_copy_index(name, np.empty(nbytes, np.uint8))
+        bad = np.nonzero(a != b)[0]
+        assert bad.size == 0, f"{name}: {bad.size} bytes differ, first at {bad[:5]}"
+    q = make_dataset(32, dim, max(nlist // 4, 1), 44, normalize=(metric == 1))
+    _compare(built, enc, q, 10, min(8, nlist))
+    ref.close(); enc.close()
