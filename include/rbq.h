@@ -195,6 +195,7 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *   "exact_rank" 1       rank all nq x nlist pairs in canonical order instead of the MFMA shortlist
  *   "force_rank_fallback" 1   send every query through the shortlist's all-lists fallback
  *   "f32_rank" 1         approximate list scores from the f32 MFMA GEMM instead of the split-bf16 one
+ *   "wg_prep" 1          workgroup-per-query query preparation for every rotator (default: one wave per query)
  *   "exact_heap" 1       keep the top-k in the BinaryHeap emulation from the first candidate (no sorted fast path) */
 int rbq_debug_set_option(rbq_index* idx, const char* name, int value);
 

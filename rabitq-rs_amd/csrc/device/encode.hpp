@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kThreads) void k_rotate_rows(const float* __restric
     const uint32_t r = blockIdx.x, tid = threadIdx.x;
     const uint32_t s = map ? map[r] : r;
     if (s == kNoSrc) return; // uniform
-    rotate_into_lds(x, y, src + (size_t)s * dim, dim, D, rotator, rot_blob, trunc, fac, tid);
+    rotate_into_lds<kThreads>(x, y, src + (size_t)s * dim, dim, D, rotator, rot_blob, trunc, fac, tid);
     for (uint32_t i = tid; i < D; i += kThreads) rows[(size_t)r * D + i] = x[i];
 }
 

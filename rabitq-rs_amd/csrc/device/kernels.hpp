@@ -109,15 +109,25 @@ __device__ __forceinline__ uint32_t block_scan_excl256(uint32_t v, uint32_t* s_w
 // ---------------------------------------------------------------------------------------------
 // k_prep: one workgroup per query.
 // ---------------------------------------------------------------------------------------------
+// Synchronisation of the GS threads that share one vector in LDS: a workgroup barrier for GS == 256; for one
+// wave (GS == 64) LDS operations of a wave are serviced in issue order, so draining them (which also stops the
+// compiler from moving LDS accesses across this point) is enough.
+template <int GS>
+__device__ __forceinline__ void group_sync() {
+    if (GS == 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
+
+template <int GS>
 __device__ __forceinline__ void fht_lds(float* a, uint32_t n, uint32_t tid) {
     for (uint32_t h = 1, lg = 0; h < n; h <<= 1, ++lg) {
-        for (uint32_t i = tid; i < n / 2; i += kThreads) {
+        for (uint32_t i = tid; i < n / 2; i += GS) {
             uint32_t j = ((i >> lg) << (lg + 1)) | (i & (h - 1));
             float x = a[j], y = a[j + h];
             a[j] = x + y;
             a[j + h] = x - y;
         }
-        __syncthreads();
+        group_sync<GS>();
     }
 }
 
@@ -141,55 +151,56 @@ __host__ __device__ inline void bf16_split(float x, uint16_t& hi, uint16_t& lo) 
     lo = bf16_rne(x - bf16_to_f32(hi));
 }
 
-// Rotator::rotate_into for one vector, by one 256-thread workgroup: the rotated vector ends up in x[0..D)
+// Rotator::rotate_into for one vector, by GS threads (one workgroup or one wave): the rotated vector ends up in x[0..D)
 // (LDS); y[0..D) is scratch for the matrix rotator.  Butterflies/adds are the reference's, stage by stage
 // (src/rotation.rs:248-401), so the result is bit-identical to the CPU path.
+template <int GS>
 __device__ __forceinline__ void rotate_into_lds(float* x, float* y, const float* __restrict__ qin, uint32_t dim, uint32_t D,
                                                 int rotator, const uint8_t* __restrict__ rot_blob, uint32_t trunc,
                                                 float fac, uint32_t tid) {
     if (rotator == 1) { // FhtKacRotator::rotate_into
-        for (uint32_t i = tid; i < D; i += kThreads) x[i] = i < dim ? qin[i] : 0.0f;
-        __syncthreads();
+        for (uint32_t i = tid; i < D; i += GS) x[i] = i < dim ? qin[i] : 0.0f;
+        group_sync<GS>();
         const uint32_t fo = D / 8;
         if (trunc == D) {
             for (int r = 0; r < 4; ++r) {
                 const uint8_t* f = rot_blob + r * fo;
-                for (uint32_t i = tid; i < D; i += kThreads)
+                for (uint32_t i = tid; i < D; i += GS)
                     if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
-                __syncthreads();
-                fht_lds(x, D, tid);
-                for (uint32_t i = tid; i < D; i += kThreads) x[i] = x[i] * fac;
-                __syncthreads();
+                group_sync<GS>();
+                fht_lds<GS>(x, D, tid);
+                for (uint32_t i = tid; i < D; i += GS) x[i] = x[i] * fac;
+                group_sync<GS>();
             }
         } else {
             const uint32_t start = D - trunc, half = D / 2;
             for (int r = 0; r < 4; ++r) {
                 const uint8_t* f = rot_blob + r * fo;
-                for (uint32_t i = tid; i < D; i += kThreads)
+                for (uint32_t i = tid; i < D; i += GS)
                     if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
-                __syncthreads();
+                group_sync<GS>();
                 float* part = (r & 1) ? x + start : x;
-                fht_lds(part, trunc, tid);
-                for (uint32_t i = tid; i < trunc; i += kThreads) part[i] = part[i] * fac;
-                __syncthreads();
-                for (uint32_t i = tid; i < half; i += kThreads) {
+                fht_lds<GS>(part, trunc, tid);
+                for (uint32_t i = tid; i < trunc; i += GS) part[i] = part[i] * fac;
+                group_sync<GS>();
+                for (uint32_t i = tid; i < half; i += GS) {
                     float a = x[i], b = x[i + half];
                     x[i] = a + b;
                     x[i + half] = a - b;
                 }
-                __syncthreads();
+                group_sync<GS>();
             }
-            for (uint32_t i = tid; i < D; i += kThreads) x[i] = x[i] * 0.25f;
-            __syncthreads();
+            for (uint32_t i = tid; i < D; i += GS) x[i] = x[i] * 0.25f;
+            group_sync<GS>();
         }
     } else if (rotator == 2) { // RBQ_ROTATOR_NONE: MSTG posting lists are quantised in the raw space
-        for (uint32_t i = tid; i < D; i += kThreads) x[i] = i < dim ? qin[i] : 0.0f;
-        __syncthreads();
+        for (uint32_t i = tid; i < D; i += GS) x[i] = i < dim ? qin[i] : 0.0f;
+        group_sync<GS>();
     } else { // MatrixRotator::rotate_into: sequential unfused accumulate per output row
-        for (uint32_t i = tid; i < D; i += kThreads) y[i] = i < dim ? qin[i] : 0.0f;
-        __syncthreads();
+        for (uint32_t i = tid; i < D; i += GS) y[i] = i < dim ? qin[i] : 0.0f;
+        group_sync<GS>();
         const float* M = reinterpret_cast<const float*>(rot_blob);
-        for (uint32_t r = tid; r < D; r += kThreads) {
+        for (uint32_t r = tid; r < D; r += GS) {
             const float* row = M + (size_t)r * D;
             float acc = 0.0f;
             for (uint32_t c = 0; c < D; ++c) {
@@ -198,7 +209,7 @@ __device__ __forceinline__ void rotate_into_lds(float* x, float* y, const float*
             }
             x[r] = acc;
         }
-        __syncthreads();
+        group_sync<GS>();
     }
 
 }
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
 
-    rotate_into_lds(x, y, qin, dim, D, rotator, rot_blob, trunc, fac, tid);
+    rotate_into_lds<kThreads>(x, y, qin, dim, D, rotator, rot_blob, trunc, fac, tid);
 
     for (uint32_t i = tid; i < D; i += kThreads) {
         rot_out[(size_t)q * D + i] = x[i];
@@ -334,6 +345,253 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         QueryConsts qc;
         qc.amin = (float)s_amin;
         qc.amax = (float)s_amax;
+        qc.delta = delta;
+        qc.sum_vl = vl * (float)(D / 4);
+        qc.qnorm = sqrtf(s_n2);
+        qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
+#ifdef RBQ_PREP_STAMPS
+        qc.pad0 = (float)(pt1 - pt0); qc.pad1 = (float)(pt2 - pt1); qc.pad2 = (float)(__builtin_amdgcn_s_memtime() - pt2);
+#endif
+        qc.k1x = -0.5f * s_sum;
+        const float cb = -((float)(1u << ex_bits) - 0.5f);
+        qc.kbx = cb * s_sum;
+        qc.scale = (float)(1u << ex_bits);
+        consts[q] = qc;
+    }
+}
+
+// In-register FHT of one wave over n = 64*EPL floats at `part` (LDS): lane holds elements lane*EPL .. +EPL-1, so
+// the stages h < EPL are register butterflies and the stages h = EPL*m (m = 1..32) exchange with lane ^ m.  Same
+// butterflies in the same stage order as fht_lds (out[j] = x[j] + x[j+h], out[j+h] = x[j] - x[j+h]), followed by
+// the reference's rescale x * fac.
+template <int EPL>
+__device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) {
+    float v[EPL];
+    if (EPL >= 4) {
+#pragma unroll
+        for (int k = 0; k < EPL; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(part + lane * EPL + k);
+            v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) v[k] = part[lane * EPL + k];
+    }
+#pragma unroll
+    for (int h = 1; h < EPL; h <<= 1)
+#pragma unroll
+        for (int k = 0; k < EPL; ++k)
+            if ((k & h) == 0) {
+                const float a = v[k], b = v[k + h];
+                v[k] = a + b;
+                v[k + h] = a - b;
+            }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const bool upper = (lane & (uint32_t)m) != 0;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const float p = __shfl_xor(v[k], m, 64);
+            v[k] = upper ? (p - v[k]) : (v[k] + p);
+        }
+    }
+    if (EPL >= 4) {
+#pragma unroll
+        for (int k = 0; k < EPL; k += 4)
+            *reinterpret_cast<float4*>(part + lane * EPL + k) = make_float4(v[k] * fac, v[k + 1] * fac, v[k + 2] * fac, v[k + 3] * fac);
+    } else {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) part[lane * EPL + k] = v[k] * fac;
+    }
+}
+
+// FhtKacRotator::rotate_into by one wave; `flips` = the 4*D/8 flip-sign bytes (LDS copy).  Same operations as
+// rotate_into_lds<64>, with fht_wave in place of the LDS butterflies.
+template <int EPL>
+__device__ __forceinline__ void rotate_fhtkac_wave(float* x, const float* __restrict__ qin, uint32_t dim, uint32_t D,
+                                                   const uint8_t* flips, float fac, uint32_t lane) {
+    constexpr uint32_t trunc = 64u * EPL;
+    for (uint32_t i = lane; i < D; i += 64) x[i] = i < dim ? qin[i] : 0.0f;
+    group_sync<64>();
+    const uint32_t fo = D / 8, start = D - trunc, half = D / 2;
+    for (int r = 0; r < 4; ++r) {
+        const uint8_t* f = flips + r * fo;
+        for (uint32_t i = lane; i < D; i += 64)
+            if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
+        group_sync<64>();
+        fht_wave<EPL>((trunc != D && (r & 1)) ? x + start : x, lane, fac);
+        group_sync<64>();
+        if (trunc != D) {
+            for (uint32_t i = lane; i < half; i += 64) {
+                const float a = x[i], b = x[i + half];
+                x[i] = a + b;
+                x[i + half] = a - b;
+            }
+            group_sync<64>();
+        }
+    }
+    if (trunc != D) {
+        for (uint32_t i = lane; i < D; i += 64) x[i] = x[i] * 0.25f;
+        group_sync<64>();
+    }
+}
+
+// pack_lut_f32 entries of one codebook: lut[j] = lut[j - lowbit(j)] + q[KPOS[j]],  KPOS = {3,3,2,3,1,3,2,3,0,3,2,3,1,3,2,3}
+__device__ __forceinline__ void lut_entries(const float* x4, float (&l)[16]) {
+    const float q0 = x4[0], q1 = x4[1], q2 = x4[2], q3 = x4[3];
+    l[0] = 0.0f;
+    l[1] = l[0] + q3;
+    l[2] = l[0] + q2;
+    l[3] = l[2] + q3;
+    l[4] = l[0] + q1;
+    l[5] = l[4] + q3;
+    l[6] = l[4] + q2;
+    l[7] = l[6] + q3;
+    l[8] = l[0] + q0;
+    l[9] = l[8] + q3;
+    l[10] = l[8] + q2;
+    l[11] = l[10] + q3;
+    l[12] = l[8] + q1;
+    l[13] = l[12] + q3;
+    l[14] = l[12] + q2;
+    l[15] = l[14] + q3;
+}
+
+// k_prep for the FHT-Kac and identity rotators with ONE WAVE per query (4 queries per workgroup): no workgroup
+// barrier anywhere — the butterflies synchronise through the wave's in-order LDS traffic, the min/max and the
+// amin/amax sums are wave reductions, and the two strictly sequential sums (sum q, |q|^2: Rust iter().sum())
+// run side by side on lanes 0 and 1 of each wave.  Same arithmetic as k_prep, operation for operation.
+// dynamic LDS: 4 x 2 x D floats (vector + squares per wave) | 4*D/8 flip bytes
+__global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t D,
+                                                        uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
+                                                        uint32_t trunc, float fac, uint32_t ex_bits,
+                                                        float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
+                                                        QueryConsts* __restrict__ consts,
+                                                        uint16_t* __restrict__ rot_hi, uint16_t* __restrict__ rot_lo) {
+    extern __shared__ __align__(16) float sm[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t q = blockIdx.x * (kThreads / 64) + wave;
+    uint8_t* flips = reinterpret_cast<uint8_t*>(sm + (size_t)2 * (kThreads / 64) * D); // 4*D/8 bytes (FHT-Kac)
+    if (rotator == 1) {
+        for (uint32_t i = threadIdx.x; i < D / 2; i += kThreads) flips[i] = rot_blob[i];
+        __syncthreads(); // the only workgroup barrier: before any wave can leave
+    }
+    if (q >= nq) return; // whole wave
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
+    float* x = sm + (size_t)wave * 2 * D;
+    float* x2 = x + D; // squares, for the |q|^2 chain
+    const float* qin = queries + (size_t)q * dim;
+    if (rotator == 1) {
+        switch (trunc) {
+            case 64: rotate_fhtkac_wave<1>(x, qin, dim, D, flips, fac, lane); break;
+            case 128: rotate_fhtkac_wave<2>(x, qin, dim, D, flips, fac, lane); break;
+            case 256: rotate_fhtkac_wave<4>(x, qin, dim, D, flips, fac, lane); break;
+            case 512: rotate_fhtkac_wave<8>(x, qin, dim, D, flips, fac, lane); break;
+            case 1024: rotate_fhtkac_wave<16>(x, qin, dim, D, flips, fac, lane); break;
+            default: rotate_fhtkac_wave<32>(x, qin, dim, D, flips, fac, lane); break;
+        }
+    } else {
+        rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, rot_blob, trunc, fac, lane);
+    }
+
+    for (uint32_t i = lane; i < D; i += 64) {
+        const float v = x[i];
+        x2[i] = v * v;
+        rot_out[(size_t)q * D + i] = v;
+        if (rot_hi) { // split-bf16 image for k_rank_bf16
+            uint16_t h, l;
+            bf16_split(v, h, l);
+            rot_hi[(size_t)q * D + i] = h;
+            rot_lo[(size_t)q * D + i] = l;
+        }
+    }
+    group_sync<64>();
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+#endif
+    // QueryPrecomputed::new — strictly sequential sums (Rust iter().sum() folds from -0.0): lane 0 adds the
+    // elements, lane 1 their squares
+    float acc = -0.0f;
+    if (lane < 2) { // 16 elements per step: four 16-byte LDS reads in flight, then the adds in element order
+        const float* src = lane ? x2 : x;
+        for (uint32_t i = 0; i < D; i += 16) { // D % 16 == 0
+            float4 v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = *reinterpret_cast<const float4*>(src + i + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = acc + v4[u].x;
+                acc = acc + v4[u].y;
+                acc = acc + v4[u].z;
+                acc = acc + v4[u].w;
+            }
+        }
+    }
+    const float s_sum = __shfl(acc, 0, 64), s_n2 = __shfl(acc, 1, 64);
+
+#ifdef RBQ_PREP_STAMPS
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
+    // pack_lut_f32 + QueryLut::new: pass 1 finds the value range, pass 2 quantises
+    const uint32_t ncb = D / 4;
+    int kmin = 0x7fffffff, kmax = (int)0x80000000;
+    for (uint32_t c = lane; c < ncb; c += 64) {
+        float l[16];
+        lut_entries(x + 4 * c, l);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = total_key(l[j]);
+            kmin = k < kmin ? k : kmin;
+            kmax = k > kmax ? k : kmax;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int a = __shfl_xor(kmin, d, 64), b = __shfl_xor(kmax, d, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    const float vl = key_to_float(kmin), vr = key_to_float(kmax);
+    const float delta = (vr - vl) / 255.0f;
+    uint32_t amin = 0, amax = 0;
+    for (uint32_t c = lane; c < Dc / 4; c += 64) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (c < ncb) {
+            float l[16];
+            lut_entries(x + 4 * c, l);
+            uint32_t emin = 255, emax = 0;
+            if (delta > 0.0f) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float v = roundf((l[j] - vl) / delta);
+                    v = v >= 0.0f ? v : 0.0f; // also maps NaN -> 0 like `as u8`
+                    v = v > 255.0f ? 255.0f : v;
+                    const uint32_t e = (uint32_t)v;
+                    emin = e < emin ? e : emin;
+                    emax = e > emax ? e : emax;
+                    w[j >> 2] |= e << (8 * (j & 3));
+                }
+            } else {
+                emin = 0;
+            }
+            amin += emin;
+            amax += emax;
+        }
+        // device LUT order: adjacent codebooks swapped (position p holds codebook p^1) so that nibble m of a
+        // little-endian code dword indexes table (8*dword + m) directly; padding codebooks are all-zero tables
+        *reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        amin += __shfl_xor(amin, d, 64);
+        amax += __shfl_xor(amax, d, 64);
+    }
+    if (lane == 0) {
+        QueryConsts qc;
+        qc.amin = (float)amin;
+        qc.amax = (float)amax;
         qc.delta = delta;
         qc.sum_vl = vl * (float)(D / 4);
         qc.qnorm = sqrtf(s_n2);

@@ -92,6 +92,7 @@ struct rbq_index {
     float cnorm2_max = 0.0f;
     bool no_block_bound = false; // rbq_debug_set_option("block_bound", 0)
     bool f32_rank = false;       // rbq_debug_set_option("f32_rank", 1): f32 MFMA GEMM instead of the split-bf16 one
+    bool wg_prep = false;        // rbq_debug_set_option("wg_prep", 1): workgroup-per-query k_prep for every rotator
     bool exact_heap = false;     // rbq_debug_set_option("exact_heap", 1): BinaryHeap emulation from the first candidate
     bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
     bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
@@ -613,11 +614,19 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
 
     {
         ProfScope ps(ix, 0, stream);
-        const size_t lds = (size_t)D * 4 * 2;
-        hipLaunchKernelGGL(k_prep, dim3((uint32_t)nq), dim3(kThreads), lds, stream, d_queries, ix->dim, D, Dc, (int)ix->rotator,
-                           (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p,
-                           (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p, split_rank ? (uint16_t*)w->rot_hi.p : nullptr,
-                           split_rank ? (uint16_t*)w->rot_lo.p : nullptr);
+        if (ix->rotator == RBQ_ROTATOR_MATRIX || ix->wg_prep) { // O(D^2) matrix rotation: one workgroup per query
+            const size_t lds = (size_t)D * 4 * 2;
+            hipLaunchKernelGGL(k_prep, dim3((uint32_t)nq), dim3(kThreads), lds, stream, d_queries, ix->dim, D, Dc, (int)ix->rotator,
+                               (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p,
+                               (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p, split_rank ? (uint16_t*)w->rot_hi.p : nullptr,
+                               split_rank ? (uint16_t*)w->rot_lo.p : nullptr);
+        } else { // FHT-Kac / identity: one wave per query
+            const uint32_t qpw = kThreads / 64;
+            hipLaunchKernelGGL(k_prep_wave, dim3((uint32_t)((nq + qpw - 1) / qpw)), dim3(kThreads), (size_t)D * 4 * 2 * qpw + D / 2, stream,
+                               d_queries, (uint32_t)nq, ix->dim, D, Dc, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc,
+                               ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p, (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p,
+                               split_rank ? (uint16_t*)w->rot_hi.p : nullptr, split_rank ? (uint16_t*)w->rot_lo.p : nullptr);
+        }
         HIP_TRY(hipGetLastError());
     }
     if (ix->exact_rank) {
@@ -1024,10 +1033,10 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
             HIP_TRY(hipMemcpyAsync(d_cnts.p, list_counts + q0, n * 4, hipMemcpyHostToDevice, st));
             {
                 ProfScope ps(ix, 0, st);
-                hipLaunchKernelGGL(k_prep, dim3((uint32_t)n), dim3(kThreads), (size_t)D * 4 * 2, st, (const float*)w->queries.p, ix->dim,
-                                   D, Dc, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, 0u,
-                                   (float*)w->rot.p, (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p, (uint16_t*)nullptr,
-                                   (uint16_t*)nullptr);
+                hipLaunchKernelGGL(k_prep_wave, dim3((uint32_t)((n + 3) / 4)), dim3(kThreads), (size_t)D * 4 * 2 * 4 + D / 2, st,
+                                   (const float*)w->queries.p, (uint32_t)n, ix->dim, D, Dc, (int)ix->rotator,
+                                   (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, 0u, (float*)w->rot.p, (uint8_t*)w->lut.p,
+                                   (QueryConsts*)w->consts.p, (uint16_t*)nullptr, (uint16_t*)nullptr);
                 HIP_TRY(hipGetLastError());
             }
             {
@@ -1103,6 +1112,7 @@ int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
     if (!std::strcmp(name, "exact_rank")) { ix->exact_rank = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "exact_heap")) { ix->exact_heap = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "f32_rank")) { ix->f32_rank = value != 0; return RBQ_OK; }
+    if (!std::strcmp(name, "wg_prep")) { ix->wg_prep = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "force_rank_fallback")) { ix->force_rank_fallback = value != 0; return RBQ_OK; }
     return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
 }
