@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--device-build", action="store_true",
+                    help="build the index with the GPU-side encoder only (large n: no CPU build, no oracle check)")
+    ap.add_argument("--kmeans-iters", type=int, default=6)
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the batches are issued on, round-robin")
     return ap.parse_args()
 
@@ -137,18 +140,43 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    def progress(msg):
+        if a.device_build and rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     t_build0 = time.time()
     x = mixture(torch, dev, a.n, a.dim, a.nlist, 20260105, a.metric == 1)
-    cent, assign = kmeans_gpu(torch, x, a.nlist, 6, 20260103)
-    x_host = x.cpu().numpy()
-    built = rq.builder.train_with_clusters(x_host, cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits,
-                                           a.metric, rq.RotatorType.FhtKacRotator, 20260104, True)
-    idx = rq.IvfRabitqIndex.from_built(built, device=local)
+    progress("data generated")
+    cent, assign = kmeans_gpu(torch, x, a.nlist, a.kmeans_iters, 20260103)
+    progress("clustered")
+    if a.device_build:
+        # header (rotator flips, t_const) from a CPU build over a tiny subset: both depend only on (padded dim, bits, seed)
+        ns = max(2 * a.nlist, 4096)
+        small = rq.builder.train_with_clusters(x[:ns].cpu().numpy(), cent.cpu().numpy(),
+                                               (torch.arange(ns) % a.nlist).numpy().astype(np.uint32), a.bits, a.metric,
+                                               rq.RotatorType.FhtKacRotator, 20260104, True)
+        built = None
+        a32 = assign.to(torch.int32).contiguous()
+        torch.cuda.synchronize(dev)
+        t0 = time.time()
+        idx = rq.IvfRabitqIndex.build_on_device(small.hdr_ptr, cent.cpu().numpy(), x.data_ptr(), a32.data_ptr(), a.n,
+                                                small.t_const, device=local)
+        t_enc_only = time.time() - t0
+        progress(f"encoded in {t_enc_only:.2f} s")
+        a.no_cpu = True
+    else:
+        x_host = x.cpu().numpy()
+        built = rq.builder.train_with_clusters(x_host, cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits,
+                                               a.metric, rq.RotatorType.FhtKacRotator, 20260104, True)
+        idx = rq.IvfRabitqIndex.from_built(built, device=local)
     t_build = time.time() - t_build0
 
     # the same index from the GPU-side encoder (rbq_index_build_device): timed and compared array by array
     encoder = None
-    if rank == 0 and a.bits in (1, 3, 7):
+    if a.device_build:
+        encoder = {"gpu_build_s": round(t_enc_only, 3), "vectors_per_s": a.n / t_enc_only, "arrays_identical_to_cpu_build": None,
+                   "note": "--device-build: the index was built by rbq_index_build_device only"}
+    elif rank == 0 and a.bits in (1, 3, 7):
         a32 = assign.to(torch.int32).contiguous()
         cent_h = cent.cpu().numpy()
         torch.cuda.synchronize(dev)
@@ -171,6 +199,7 @@ def main():
     # every rank draws its own query batch from the same mixture (different stream per rank)
     q = mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102 + rank, a.metric == 1).contiguous()
     gt = exact_topk(torch, x, q, a.top_k, a.metric)
+    progress("ground truth done")
     del x
     torch.cuda.empty_cache()
 
@@ -179,8 +208,9 @@ def main():
     d_ids = [torch.empty(a.batch, a.top_k, dtype=torch.int64, device=dev) for _ in range(ns)]  # u64 bit patterns
     d_sc = [torch.empty(a.batch, a.top_k, dtype=torch.float32, device=dev) for _ in range(ns)]
     d_cnt = [torch.empty(a.batch, dtype=torch.int32, device=dev) for _ in range(ns)]
-    g_ids = [torch.empty_like(d_ids[0]) for _ in range(world)] if world > 1 else None
-    g_sc = [torch.empty_like(d_sc[0]) for _ in range(world)] if world > 1 else None
+    # gather targets of the final top-k exchange: one set per stream, so overlapping batches never share a buffer
+    g_ids = [[torch.empty_like(d_ids[0]) for _ in range(world)] for _ in range(ns)] if world > 1 else None
+    g_sc = [[torch.empty_like(d_sc[0]) for _ in range(world)] for _ in range(ns)] if world > 1 else None
     step_no = [0]
 
     def step():
@@ -190,8 +220,8 @@ def main():
                                 d_cnt[i].data_ptr(), stream=streams[i].cuda_stream)
         if world > 1:  # the path's only exchange: final top-k gather over RCCL/xGMI
             with torch.cuda.stream(streams[i]):
-                dist.all_gather(g_ids, d_ids[i])
-                dist.all_gather(g_sc, d_sc[i])
+                dist.all_gather(g_ids[i], d_ids[i])
+                dist.all_gather(g_sc[i], d_sc[i])
 
     def fence():
         if world > 1:
