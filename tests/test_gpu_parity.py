@@ -386,3 +386,20 @@ def test_device_encoder_matches_cpu_builder(n, dim, nlist, bits, metric, rot):
     q = make_dataset(32, dim, max(nlist // 4, 1), 44, normalize=(metric == 1))
     _compare(built, enc, q, 10, min(8, nlist))
     ref.close(); enc.close()
+
+
+def test_device_encoder_rejects_bad_input():
+    """rbq_index_build_device: an assignment outside [0, n_lists) and a missing constant rescale factor are
+    configuration errors (RabitqError::InvalidConfig), reported without touching the GPU index."""
+    import torch
+    data, built = build_index(n=2000, dim=64, nlist=8, total_bits=7, seed=51)
+    cent = np.zeros((8, 64), np.float32)
+    xd = torch.from_numpy(data).cuda()
+    bad = torch.full((2000,), 8, dtype=torch.int32).cuda()
+    with pytest.raises(rq.RabitqError) as e:
+        rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), bad.data_ptr(), 2000, built.t_const)
+    assert e.value.kind == "InvalidConfig"
+    ok = torch.zeros(2000, dtype=torch.int32).cuda()
+    with pytest.raises(rq.RabitqError) as e:
+        rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ok.data_ptr(), 2000, 0.0)
+    assert e.value.kind == "InvalidConfig"
