@@ -5,18 +5,23 @@
 // lower-bound pruning + ip_packed_ex{2,6}_f32 (:1835-1915) + BinaryHeap top-k (src/ivf.rs:904-931).
 //
 // One workgroup = one query, with fixed wave roles:
-//   waves 0..NS-1 "scanners": stream the query's block work list, 2*NS blocks (64*NS candidates) per tile,
-//             lane = vector; the codes of tile t+1 are prefetched into registers while tile t is looked up
-//             in LDS; survivors (lb < T) are published (mask, lb, ip, est, slot) to a double-buffered LDS queue.
-//   wave NS   "replay wave": compacts the previous tile's survivors in stream order, refines them (16 lanes
-//             per survivor over a lane-major copy of the ex codes) and replays them through the reference's
-//             exact prune/push/pop loop — a Rust-BinaryHeap-faithful heap held in the wave's registers
-//             (v_readlane/v_writelane) — while the scanners are already on the next tile; publishes T.
+//   waves 0..NS-1 "scanners": consume the query's block stream (k_select_mfma: probe order, block order inside a
+//             list, each entry with its precomputed block-level lower bound) in fill steps (one lane per entry:
+//             bound vs threshold -> live-block FIFO) and tile steps (2*NS live blocks, lane = vector: codes ->
+//             LDS LUT lookups -> fused epilogue); survivors (lb < T) are published (mask, lb, ip, est, slot) to a
+//             double-buffered LDS queue.
+//   wave NS   "replay wave": compacts the previous tile's survivors in stream order, refines lazily (only
+//             survivors still below the true threshold, 16 lanes per survivor over a lane-major copy of the ex
+//             codes) and replays them through the reference's exact prune/push/pop loop while the scanners are
+//             already on the next tile; publishes T.  The top-k lives in the wave's registers: a sorted run while
+//             all distances are distinct, the Rust-BinaryHeap-faithful RegHeap after an in-kernel restart
+//             otherwise (see SortedTop).
 // Exactness: scanners prune with a STALE threshold T.  T only ever shrinks, so `lb >= T_stale` implies the
 // reference (whose threshold at that moment is <= T_stale) skipped the candidate too; everything else is
 // re-tested by the replay wave against the true running threshold, in stream order.  ids therefore equal
 // the sequential CPU path bit for bit.  Tiles with more than kLightMax survivors (the first probed lists,
-// where T is still loose) run synchronously: every wave refines and the scanners wait for the fresh T.
+// where T is still loose) run synchronously, software-pipelined: the scanners' groups refine batch r+1 while
+// the replay wave replays batch r.
 #pragma once
 #include "kernels.hpp"
 
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
   for (;;) { // a second pass only after a tie on the sorted fast path
     while (true) {
         if (pos < ns && qcount < (uint32_t)kTileBlocks) {
-            // ---------------------------------------------------------------- fill step: examine kWindow blocks
+            // ---------------------------------------------------------------- fill step: examine `win` stream entries
             STAMP(st_c);
             if (scanner) {
                 // one lane per block: stream entry (with its precomputed block-level bound) vs the threshold
