@@ -197,10 +197,13 @@ __global__ __launch_bounds__(256) void k_rank_bf16(const uint16_t* __restrict__ 
             for (int a = 0; a < TW; ++a)
 #pragma unroll
                 for (int b = 0; b < TW; ++b) {
-                    // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used: with it, workgroups of OTHER
-                    // kernels resident on the same SIMDs (k_prep of a neighbouring stream) computed wrong values —
-                    // one 16-lane pass of a quantisation result at a time, tools/stress3.py — on this hardware pool.
-                    // The K=8 form below is clean under the same stress (tests/test_gpu_parity.py multi-stream test).
+                    // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used.  With it in this GEMM, the
+                    // workgroup-per-query k_prep of a NEIGHBOURING stream computed wrong LUT bytes (one 16-lane pass
+                    // of a quantisation result at a time, tools/stress3.py) although neither kernel writes outside
+                    // its own buffers; the K=8 form below never showed it, nor does k_prep_wave with either form,
+                    // and a stand-alone MFMA-beside-division test (tools/repro/) stays clean.  Root cause not
+                    // established; the combination that ships is the one every stress run has been clean with
+                    // (tests/test_gpu_parity.py::test_concurrent_streams_match_oracle guards it).
 #ifdef RBQ_MFMA_X16
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
