@@ -396,12 +396,19 @@ struct SortedTop { // operates on the registers of a RegHeap (only one of the tw
 //   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
 //   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
 //   T, len, nskip, nbatch | batch[kScanThreads/16] u32
-constexpr int kWindow = kNScan * 64;               // blocks examined per fill step: one per scanner lane
-constexpr int kQueueCap = 256;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
+#ifndef RBQ_FILL_K
+#define RBQ_FILL_K 2
+#endif
+#ifndef RBQ_WIN_GROW
+#define RBQ_WIN_GROW 4
+#endif
+constexpr int kFillK = RBQ_FILL_K;                 // stream entries per scanner lane and fill step
+constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
+constexpr int kQueueCap = 512;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 __host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
     return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * 8 + 32 + (kScanThreads / 16) * 4;
+           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 4;
 }
 
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
@@ -422,9 +429,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t* s_list = reinterpret_cast<uint32_t*>(q_d + 2 * kTileCand); // [kTileCand] survivor positions, stream order
     uint32_t* s_mask = s_list + kTileCand;                                // [2][kTileBlocks]
     WorkItem* s_queue = reinterpret_cast<WorkItem*>(s_mask + 2 * kTileBlocks); // [kQueueCap] live blocks, stream order
-    unsigned long long* s_fmask = reinterpret_cast<unsigned long long*>(s_queue + kQueueCap); // [kNScan] fill-step live masks
+    unsigned long long* s_fmask = reinterpret_cast<unsigned long long*>(s_queue + kQueueCap); // [kFillK][kNScan] fill-step live masks
     // no static __shared__ in this kernel: the dynamic region must start at LDS address 0 (see lds_lut_ptr)
-    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_fmask + kNScan);
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_fmask + kNScan * kFillK);
     float& s_T = *reinterpret_cast<float*>(s_misc);
     uint32_t& s_len = *(s_misc + 1);
     uint32_t* s_nskip = s_misc + 2;
@@ -533,7 +540,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t tile = 0;                // tiles published so far (buffer = tile & 1)
     // Blocks examined by the next fill step.  The first steps are small: with the threshold still at +inf the
     // block bound passes everything, and whatever is queued then is paid for at tile time (factor rows, a
-    // barrier, usually no survivor).  Once the nearest lists have set a threshold the windows grow.
+    // barrier, usually no survivor).  Once the nearest lists have set a threshold the windows grow
+    // (x RBQ_WIN_GROW per step, up to kFillK entries per scanner lane).
     uint32_t win = (uint32_t)kTileBlocks;
     // replay-wave state
     const bool reg_heap = top_k < 64;
@@ -562,45 +570,61 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             // ---------------------------------------------------------------- fill step: examine `win` stream entries
             STAMP(st_c);
             if (scanner) {
-                // one lane per block: stream entry (with its precomputed block-level bound) vs the threshold
+                // kFillK stream entries per lane (entry k*192 + lane slot of the window): precomputed block-level
+                // bound vs the threshold; compaction in stream order = (k, wave, lane) order
                 const float T = s_T;
                 const uint32_t wslot = wave * 64u + lane;
-                const uint32_t idx = pos + wslot;
-                WorkItem w;
-                w.gblock = 0; w.rank_nvalid = 0;
-                bool live = false;
-                if (wslot < win && idx < ns) {
-                    const StreamItem si = wl[idx];
-                    w.gblock = si.gblock; w.rank_nvalid = si.rank_nvalid;
-                    live = true;
-                    if (bound_ok && si.lbmin >= T) { // block_lbmin(): no real vector of the block can pass
-                        live = false;
-                        if (count_skips) n_skip += w.rank_nvalid & 63u;
+                WorkItem w[kFillK];
+                bool live[kFillK];
+                StreamItem si[kFillK];
+#pragma unroll
+                for (int k = 0; k < kFillK; ++k) {
+                    const uint32_t wk = (uint32_t)k * (kNScan * 64u) + wslot;
+                    si[k].gblock = 0; si[k].rank_nvalid = 0; si[k].lbmin = 0.0f; si[k].pad = 0;
+                    live[k] = wk < win && pos + wk < ns;
+                    if (live[k]) si[k] = wl[pos + wk];
+                }
+                unsigned long long lm[kFillK];
+#pragma unroll
+                for (int k = 0; k < kFillK; ++k) {
+                    w[k].gblock = si[k].gblock; w[k].rank_nvalid = si[k].rank_nvalid;
+                    if (live[k] && bound_ok && si[k].lbmin >= T) { // block_lbmin(): no real vector of the block can pass
+                        live[k] = false;
+                        if (count_skips) n_skip += w[k].rank_nvalid & 63u;
+                    }
+                    lm[k] = __ballot(live[k]);
+                    if (lane == 0) s_fmask[k * kNScan + wave] = lm[k];
+                }
+                lds_barrier(); // X1: live masks published
+                uint32_t total = 0;
+#pragma unroll
+                for (int j = 0; j < kNScan * kFillK; ++j) total += __popcll(s_fmask[j]);
+                {
+                    uint32_t base = 0; // running count of the sub-windows before k
+#pragma unroll
+                    for (int k = 0; k < kFillK; ++k) {
+                        uint32_t cnt_k = 0;
+#pragma unroll
+                        for (int j = 0; j < kNScan; ++j) cnt_k += __popcll(s_fmask[k * kNScan + j]);
+                        uint32_t offk = 0;
+#pragma unroll
+                        for (int j = 0; j < kNScan; ++j) if ((uint32_t)j < wave) offk += __popcll(s_fmask[k * kNScan + j]);
+                        if (live[k]) s_queue[(qhead + qcount + base + offk + __popcll(lm[k] & ((1ull << lane) - 1ull))) % kQueueCap] = w[k];
+                        base += cnt_k;
                     }
                 }
-                const unsigned long long livemask = __ballot(live);
-                if (lane == 0) s_fmask[wave] = livemask;
-                lds_barrier(); // X1: live masks published
-                uint32_t off = 0, total = 0;
-#pragma unroll
-                for (int j = 0; j < kNScan; ++j) {
-                    const uint32_t c = __popcll(s_fmask[j]);
-                    off += (uint32_t)j < wave ? c : 0u;
-                    total += c;
-                }
-                if (live) s_queue[(qhead + qcount + off + __popcll(livemask & ((1ull << lane) - 1ull))) % kQueueCap] = w;
                 lds_barrier(); // X2: queue entries visible
                 qcount += total;
             } else {
                 lds_barrier(); // X1
                 uint32_t total = 0;
 #pragma unroll
-                for (int j = 0; j < kNScan; ++j) total += __popcll(s_fmask[j]);
+                for (int j = 0; j < kNScan * kFillK; ++j) total += __popcll(s_fmask[j]);
                 lds_barrier(); // X2
                 qcount += total;
             }
             pos += win;
-            win = win * 2u < (uint32_t)kWindow ? win * 2u : (uint32_t)kWindow;
+            win = win * (uint32_t)RBQ_WIN_GROW < (uint32_t)kWindow ? win * (uint32_t)RBQ_WIN_GROW : (uint32_t)kWindow;
 #ifdef RBQ_STAMPS
             STAMP(st_b); st_fill += st_b - st_c;
 #endif
