@@ -640,12 +640,15 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             wi_c.gblock = 0; wi_c.rank_nvalid = 0;
             if (hw < n) wi_c = s_queue[(qhead + hw) % kQueueCap];
             const uint8_t* blk = P.blocks + (size_t)wi_c.gblock * stride;
+            // The codes are requested together with the factor rows, not after the bound below: a queued block
+            // already passed the block-level bound of the fill step, so it is almost always still alive, and the
+            // two memory round trips overlap (the runtime-dimension path keeps the lazy order).
+            CodeRegs<DT> cc;
+            if (DT && hw < n) load_codes<DT>(cc, blk, l32);
             const Meta m_c = load_meta(wi_c);
             const float T = s_T;
-            // per-lane bound with the fresh threshold: the whole wave may be prunable without reading codes
+            // per-lane bound with the fresh threshold: the whole wave may be prunable without looking anything up
             const bool live_c = !bound_ok || (__ballot(lane_prunable(wi_c, m_c, T)) != ~0ull);
-            CodeRegs<DT> cc;
-            if (DT && live_c) load_codes<DT>(cc, blk, l32);
             const uint32_t nvalid = wi_c.rank_nvalid & 63u;
             const uint32_t slot = wi_c.gblock * 32u + l32;
             bool valid = l32 < nvalid;
