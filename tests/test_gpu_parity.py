@@ -403,3 +403,30 @@ def test_device_encoder_rejects_bad_input():
     with pytest.raises(rq.RabitqError) as e:
         rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ok.data_ptr(), 2000, 0.0)
     assert e.value.kind == "InvalidConfig"
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    rot = int(rng.integers(0, 2))
+    dim = int(rng.choice([16, 24, 40, 64, 96, 100, 128, 200, 256, 384, 512, 768])) if rot == 1 else int(rng.choice([16, 32, 48, 64, 96, 128]))
+    bits = int(rng.choice([1, 3, 7]))
+    metric = int(rng.integers(0, 2))
+    nlist = int(rng.integers(2, 60))
+    n = int(rng.integers(max(nlist, 40), 4000))
+    nq = int(rng.integers(1, 40))
+    top_k = int(rng.choice([1, 2, 5, 10, 17, 64, 100]))
+    nprobe = int(rng.integers(1, nlist + 3))
+    return n, dim, nlist, bits, metric, rot, nq, top_k, nprobe
+
+
+@pytest.mark.parametrize("seed", list(range(100, 124)))
+def test_random_configurations_match_oracle(seed):
+    """Seeded random shapes (dimension padding, tiny lists, nprobe > nlist, top_k beyond the candidate count,
+    top_k >= 64 = LDS heap, both metrics, both rotators): ids, counts, scores and diagnostics equal the oracle's."""
+    n, dim, nlist, bits, metric, rot, nq, top_k, nprobe = _random_case(seed)
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot, seed=seed,
+                              normalize=(metric == 1))
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(nq, dim, max(nlist // 4, 1), seed + 1000, normalize=(metric == 1))
+    _compare(built, idx, q, top_k, nprobe)
+    idx.close()
