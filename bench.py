@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--device-build", action="store_true",
                     help="build the index with the GPU-side encoder only (large n: no CPU build, no oracle check)")
     ap.add_argument("--kmeans-iters", type=int, default=6)
+    ap.add_argument("--option", action="append", default=[], help="rbq_debug_set_option name=value (diagnostic A/B runs)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the batches are issued on, round-robin")
     return ap.parse_args()
 
@@ -199,6 +200,10 @@ def main():
                    "note": "rbq_index_build_device: rotate + quantize_with_centroid (faster config) + device layout, "
                            "clustering excluded; the CPU figure (index_build_s) also contains data generation, "
                            "k-means and the upload"}
+
+    for kv in a.option:
+        k, v = kv.split("=")
+        idx.set_option(k, int(v))
 
     # every rank draws its own query batch from the same mixture (different stream per rank)
     q = mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102 + rank, a.metric == 1).contiguous()

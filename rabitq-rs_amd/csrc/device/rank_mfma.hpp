@@ -114,68 +114,85 @@ __device__ __forceinline__ f32x16 mfma_x8(bf16x8 a, bf16x8 b, f32x16 c) {
 // Split-bf16 GEMM: 64*TW x 64*TW tile per 256-thread workgroup, K slabs of 64 staged through LDS (rows padded to
 // 144 bytes: the 16 lanes of a ds_read_b128 group then hit 16 distinct 4-bank sets), next slab prefetched into
 // registers while the current one feeds the MFMAs.  D % 64 == 0.
-// dynamic LDS: Ah | Al | Bh | Bl, each [64*TW][144 B]
-template <int METRIC, int TW>
-__global__ __launch_bounds__(256) void k_rank_bf16(const uint16_t* __restrict__ rot_hi, const uint16_t* __restrict__ rot_lo,
+// dynamic LDS: Ah | Al [BM][144 B] | Bh | Bl [BN][144 B]
+template <int METRIC, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16(const uint16_t* __restrict__ rot_hi, const uint16_t* __restrict__ rot_lo,
                                                    const uint16_t* __restrict__ cent_hi, const uint16_t* __restrict__ cent_lo,
                                                    const QueryConsts* __restrict__ consts,
                                                    const float* __restrict__ cnorm2, uint32_t nq, uint32_t nlist,
                                                    uint32_t D, float* __restrict__ scores) {
-    constexpr int BM = 64 * TW, BK = 64, LDB = BK * 2 + 16, SEG = BK / 8, NL = BM * SEG / 256; // NL 16-byte loads per thread and array
+    constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, BK = 64, LDB = BK * 2 + 16, SEG = BK / 8;
+    constexpr int NLA = BM * SEG / NT, NLB = BN * SEG / NT; // 16-byte loads per thread and array
+    static_assert(BM * SEG % NT == 0 && BN * SEG % NT == 0, "tile rows must divide over the threads");
     extern __shared__ __align__(16) unsigned char smraw[];
     unsigned char* sAh = smraw;
     unsigned char* sAl = sAh + BM * LDB;
     unsigned char* sBh = sAl + BM * LDB;
-    unsigned char* sBl = sBh + BM * LDB;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w >> 1, wn = w & 1u;
-    const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BM;
-    f32x16 acc[TW][TW];
+    unsigned char* sBl = sBh + BN * LDB;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w / WN, wn = w % WN;
+    const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BN;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < TW; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TW; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     // per-thread source rows (clamped: rows past the end compute scores that are never stored) and LDS slots
-    const unsigned char* ga_h[NL];
-    const unsigned char* ga_l[NL];
-    const unsigned char* gb_h[NL];
-    const unsigned char* gb_l[NL];
-    uint32_t so[NL];
+    const unsigned char* ga_h[NLA];
+    const unsigned char* ga_l[NLA];
+    const unsigned char* gb_h[NLB];
+    const unsigned char* gb_l[NLB];
+    uint32_t soa[NLA], sob[NLB];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const uint32_t idx = tid + 256u * i, row = idx / SEG, seg = idx % SEG;
-        const uint32_t ra = q0 + row < nq ? q0 + row : nq - 1u, rb = c0 + row < nlist ? c0 + row : nlist - 1u;
+    for (int i = 0; i < NLA; ++i) {
+        const uint32_t idx = tid + (uint32_t)NT * i, row = idx / SEG, seg = idx % SEG;
+        const uint32_t ra = q0 + row < nq ? q0 + row : nq - 1u;
         ga_h[i] = reinterpret_cast<const unsigned char*>(rot_hi) + (size_t)ra * D * 2 + seg * 16;
         ga_l[i] = reinterpret_cast<const unsigned char*>(rot_lo) + (size_t)ra * D * 2 + seg * 16;
+        soa[i] = row * LDB + seg * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const uint32_t idx = tid + (uint32_t)NT * i, row = idx / SEG, seg = idx % SEG;
+        const uint32_t rb = c0 + row < nlist ? c0 + row : nlist - 1u;
         gb_h[i] = reinterpret_cast<const unsigned char*>(cent_hi) + (size_t)rb * D * 2 + seg * 16;
         gb_l[i] = reinterpret_cast<const unsigned char*>(cent_lo) + (size_t)rb * D * 2 + seg * 16;
-        so[i] = row * LDB + seg * 16;
+        sob[i] = row * LDB + seg * 16;
     }
-    u32x4 pah[NL], pal[NL], pbh[NL], pbl[NL]; // native vectors: the HIP uint4 struct kept these arrays in scratch
+    u32x4 pah[NLA], pal[NLA], pbh[NLB], pbl[NLB]; // native vectors: the HIP uint4 struct kept these arrays in scratch
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
+    for (int i = 0; i < NLA; ++i) {
         pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i]);
         pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
         pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i]);
         pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i]);
     }
     for (uint32_t k0 = 0; k0 < D; k0 += BK) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            *reinterpret_cast<u32x4*>(sAh + so[i]) = pah[i];
-            *reinterpret_cast<u32x4*>(sAl + so[i]) = pal[i];
-            *reinterpret_cast<u32x4*>(sBh + so[i]) = pbh[i];
-            *reinterpret_cast<u32x4*>(sBl + so[i]) = pbl[i];
+        for (int i = 0; i < NLA; ++i) {
+            *reinterpret_cast<u32x4*>(sAh + soa[i]) = pah[i];
+            *reinterpret_cast<u32x4*>(sAl + soa[i]) = pal[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            *reinterpret_cast<u32x4*>(sBh + sob[i]) = pbh[i];
+            *reinterpret_cast<u32x4*>(sBl + sob[i]) = pbl[i];
         }
         __syncthreads();
         {
             const uint32_t kn = k0 + BK < D ? k0 + BK : k0; // last slab: reload (unused)
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
+            for (int i = 0; i < NLA; ++i) {
                 pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i] + (size_t)kn * 2);
                 pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i] + (size_t)kn * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) {
                 pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i] + (size_t)kn * 2);
                 pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i] + (size_t)kn * 2);
             }
@@ -184,19 +201,23 @@ __global__ __launch_bounds__(256) void k_rank_bf16(const uint16_t* __restrict__ 
         for (int kc = 0; kc < BK / 16; ++kc) {
             // A/B operand of 32x32x16: lane l holds row (l & 31), k = 8 * (l >> 5) .. + 7
             const uint32_t fo = (lane & 31u) * LDB + kc * 32 + (lane >> 5) * 16;
-            bf16x8 ah[TW], al[TW], bh[TW], bl[TW];
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int a = 0; a < TW; ++a) {
-                const uint32_t ra = (wm * 32 * TW + a * 32) * LDB + fo, rb = (wn * 32 * TW + a * 32) * LDB + fo;
+            for (int a = 0; a < TM; ++a) {
+                const uint32_t ra = (wm * 32 * TM + a * 32) * LDB + fo;
                 ah[a] = *reinterpret_cast<const bf16x8*>(sAh + ra);
                 al[a] = *reinterpret_cast<const bf16x8*>(sAl + ra);
-                bh[a] = *reinterpret_cast<const bf16x8*>(sBh + rb);
-                bl[a] = *reinterpret_cast<const bf16x8*>(sBl + rb);
             }
 #pragma unroll
-            for (int a = 0; a < TW; ++a)
+            for (int b = 0; b < TN; ++b) {
+                const uint32_t rb = (wn * 32 * TN + b * 32) * LDB + fo;
+                bh[b] = *reinterpret_cast<const bf16x8*>(sBh + rb);
+                bl[b] = *reinterpret_cast<const bf16x8*>(sBl + rb);
+            }
 #pragma unroll
-                for (int b = 0; b < TW; ++b) {
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
                     // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used.  With it in this GEMM, the
                     // workgroup-per-query k_prep of a NEIGHBOURING stream computed wrong LUT bytes (one 16-lane pass
                     // of a quantisation result at a time, tools/stress3.py) although neither kernel writes outside
@@ -220,14 +241,14 @@ __global__ __launch_bounds__(256) void k_rank_bf16(const uint16_t* __restrict__ 
     }
     // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int a = 0; a < TW; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TW; ++b) {
-            const uint32_t c = c0 + wn * 32 * TW + b * 32 + (lane & 31u);
+        for (int b = 0; b < TN; ++b) {
+            const uint32_t c = c0 + wn * 32 * TN + b * 32 + (lane & 31u);
             const float cn = (METRIC == 0 && c < nlist) ? cnorm2[c] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t qi = q0 + wm * 32 * TW + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const uint32_t qi = q0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (qi < nq && c < nlist) {
                     const float dot = acc[a][b][r];
                     float v = dot;

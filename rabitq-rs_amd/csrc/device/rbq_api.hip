@@ -92,6 +92,7 @@ struct rbq_index {
     float cnorm2_max = 0.0f;
     bool no_block_bound = false; // rbq_debug_set_option("block_bound", 0)
     bool f32_rank = false;       // rbq_debug_set_option("f32_rank", 1): f32 MFMA GEMM instead of the split-bf16 one
+    bool small_rank_tiles = false; // rbq_debug_set_option("small_rank_tiles", 1): 64x64 GEMM tiles whatever the problem size
     bool wg_prep = false;        // rbq_debug_set_option("wg_prep", 1): workgroup-per-query k_prep for every rotator
     bool exact_heap = false;     // rbq_debug_set_option("exact_heap", 1): BinaryHeap emulation from the first candidate
     bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
@@ -655,26 +656,28 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
     } else {
         {
             ProfScope ps(ix, 1, stream); // approximate scores: one MFMA GEMM
-            const bool big = (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
+            const bool big = !ix->small_rank_tiles && (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
             const uint32_t T = big ? 128u : 64u;
             dim3 grid((nlist + T - 1) / T, (uint32_t)((nq + T - 1) / T));
             if (split_rank) {
-                const size_t lds = (size_t)T * 144 * 4;
-#define RBQ_LAUNCH_RANKB(M, TW)                                                                                        \
+                // big problems: 128x128 tiles, 8 waves (each 64x32) — the tile traffic of the 4-wave form with twice
+                // the waves to hide the staging behind the MFMAs; small ones: 64x64 tiles, 4 waves
+#define RBQ_LAUNCH_RANKB(M, TM, TN, WM, WN)                                                                            \
     do {                                                                                                               \
+        const size_t lds = (size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 144;                                        \
         static std::atomic<int> attr_dev_mask{0}; /* once per device: the call is slow and serialises launches */      \
         if (lds > 48 * 1024 && !(attr_dev_mask.load() & (1 << ix->device))) {                                          \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_bf16<M, TW>),                            \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_bf16<M, TM, TN, WM, WN>),                \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
             attr_dev_mask.fetch_or(1 << ix->device);                                                                   \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_rank_bf16<M, TW>), grid, dim3(256), lds, stream, (const uint16_t*)w->rot_hi.p,           \
-                           (const uint16_t*)w->rot_lo.p, (const uint16_t*)ix->d_cent_hi, (const uint16_t*)ix->d_cent_lo, \
-                           (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2, (uint32_t)nq, nlist, D,       \
-                           (float*)w->scores.p);                                                                       \
+        hipLaunchKernelGGL((k_rank_bf16<M, TM, TN, WM, WN>), grid, dim3(64 * WM * WN), lds, stream,                    \
+                           (const uint16_t*)w->rot_hi.p, (const uint16_t*)w->rot_lo.p, (const uint16_t*)ix->d_cent_hi, \
+                           (const uint16_t*)ix->d_cent_lo, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2, \
+                           (uint32_t)nq, nlist, D, (float*)w->scores.p);                                               \
     } while (0)
-                if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANKB(0, 2); else RBQ_LAUNCH_RANKB(0, 1); }
-                else { if (big) RBQ_LAUNCH_RANKB(1, 2); else RBQ_LAUNCH_RANKB(1, 1); }
+                if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANKB(0, 2, 1, 2, 4); else RBQ_LAUNCH_RANKB(0, 1, 1, 2, 2); }
+                else { if (big) RBQ_LAUNCH_RANKB(1, 2, 1, 2, 4); else RBQ_LAUNCH_RANKB(1, 1, 1, 2, 2); }
 #undef RBQ_LAUNCH_RANKB
             } else {
 #define RBQ_LAUNCH_RANK(M, TW)                                                                                         \
@@ -1113,6 +1116,7 @@ int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
     if (!std::strcmp(name, "exact_heap")) { ix->exact_heap = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "f32_rank")) { ix->f32_rank = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "wg_prep")) { ix->wg_prep = value != 0; return RBQ_OK; }
+    if (!std::strcmp(name, "small_rank_tiles")) { ix->small_rank_tiles = value != 0; return RBQ_OK; }
     if (!std::strcmp(name, "force_rank_fallback")) { ix->force_rank_fallback = value != 0; return RBQ_OK; }
     return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
 }
