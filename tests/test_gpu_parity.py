@@ -430,3 +430,27 @@ def test_random_configurations_match_oracle(seed):
     q = make_dataset(nq, dim, max(nlist // 4, 1), seed + 1000, normalize=(metric == 1))
     _compare(built, idx, q, top_k, nprobe)
     idx.close()
+
+
+def test_gpu_matches_committed_vectors():
+    """The committed golden vectors (tests/golden/oracle_vectors.npz: ids, scores, counts, diagnostics of seeded
+    cases) through the GPU path — independent of whatever oracle library is on the box."""
+    import importlib.util
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.join(g, "make_oracle_vectors.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    want = np.load(os.path.join(g, "oracle_vectors.npz"))
+    for name, n, dim, nlist, bits, metric, rot, nq, top_k, nprobe in gen.CASES:
+        data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot, seed=2026,
+                                  normalize=(metric == 1))
+        q = make_dataset(nq, dim, max(nlist // 4, 1), 2027, normalize=(metric == 1))
+        idx = rq.IvfRabitqIndex.from_built(built)
+        ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe), want_diag=True)
+        assert np.array_equal(ids, want[f"{name}/ids"]), name
+        assert np.array_equal(cnt, want[f"{name}/counts"]), name
+        assert np.array_equal(diag, want[f"{name}/diag"]), name
+        w = want[f"{name}/scores"]
+        ok = np.isfinite(w)
+        np.testing.assert_allclose(sc[ok], w[ok], rtol=RTOL, atol=0)
+        idx.close()

@@ -10,8 +10,13 @@ import rabitq_rs_amd as rq
 from conftest import build_index, make_dataset
 from rabitq_rs_amd import builder
 
+import json
+import os
+
 L = oracle.lib
 B = builder.lib
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "reference_kats.json")))
 
 
 def _pack_bits(bits):
@@ -26,10 +31,8 @@ def test_pack_1bit_known_answers():
     def p1(v):
         v = np.asarray(v, np.uint16); out = np.zeros(len(v) // 8, np.uint8)
         B().rbq_build_pack_ex_code_1bit(v.ctypes.data, out.ctypes.data, len(v)); return out.tolist()
-    assert p1([i % 2 for i in range(16)]) == [0xAA, 0xAA]          # 0xAAAA LE
-    assert p1([0] * 16) == [0x00, 0x00]
-    assert p1([1] * 16) == [0xFF, 0xFF]
-    assert p1([1] * 8 + [0] * 8) == [0xFF, 0x00]                    # 0x00FF LE
+    for case in KATS["pack_1bit"]["cases"]:  # tests/golden/reference_kats.json (src/simd.rs:2789-2846)
+        assert p1(case["codes"]) == case["bytes"]
 
 
 def test_pack_2bit_known_answers():
@@ -37,11 +40,13 @@ def test_pack_2bit_known_answers():
         v = np.asarray(v, np.uint16); out = np.zeros(len(v) // 4, np.uint8)
         B().rbq_build_pack_ex_code_2bit(v.ctypes.data, out.ctypes.data, len(v)); return out
     # [0,1,2,3]x4 -> byte i holds codes i, i+4, i+8, i+12 = (i&3) four times -> 00 55 AA FF
-    assert p2([0, 1, 2, 3] * 4).tolist() == [0x00, 0x55, 0xAA, 0xFF]
+    for case in KATS["pack_2bit"]["cases"]:
+        assert p2(case["codes"]).tolist() == case["bytes"]
     # inverse known answer: bytes [0x94,0xF0,0x00,0xFF] -> codes 0,4,8,12 = 0,1,1,2 (src/simd.rs:2966-2984)
-    w = int.from_bytes(bytes([0x94, 0xF0, 0x00, 0xFF]), "little")
+    u = KATS["pack_2bit"]["unpack"]
+    w = int.from_bytes(bytes(u["bytes"]), "little")
     code = lambda l: (w >> (8 * (l & 3) + 2 * (l >> 2))) & 3
-    assert [code(0), code(4), code(8), code(12)] == [0, 1, 1, 2]
+    assert [code(l) for l in u["positions"]] == u["codes"]
     # round trip at D=960 through the oracle's reader formula
     rng = np.random.default_rng(0)
     c = rng.integers(0, 4, 960).astype(np.uint16)
@@ -54,8 +59,8 @@ def test_pack_6bit_known_answers():
     def p6(v):
         v = np.asarray(v, np.uint16); out = np.zeros(len(v) * 6 // 8, np.uint8)
         B().rbq_build_pack_ex_code_6bit(v.ctypes.data, out.ctypes.data, len(v)); return out
-    assert p6([0] * 16).tolist() == [0] * 12
-    assert p6([63] * 16).tolist() == [0xFF] * 12
+    for case in KATS["pack_6bit"]["cases"]:
+        assert p6([case["codes_all"]] * case["n"]).tolist() == [case["bytes_all"]] * case["nbytes"]
     rng = np.random.default_rng(1)
     c = rng.integers(0, 64, 960).astype(np.uint16)
     pk = p6(c)
@@ -65,20 +70,25 @@ def test_pack_6bit_known_answers():
 
 def test_binary_code_msb_first():
     # bit i -> byte i/8, bit 7-(i%8)  (src/simd.rs:141-150)
-    bits = np.zeros(16, np.uint8); bits[0] = 1; bits[15] = 1
-    assert _pack_bits(bits).tolist() == [0x80, 0x01]
+    k = KATS["binary_code_msb_first"]
+    bits = np.zeros(k["dim"], np.uint8); bits[k["set_bits"]] = 1
+    assert _pack_bits(bits).tolist() == k["bytes"]
 
 
 # ---- ex-code dot dispatch literals (src/simd.rs:3222-3258) ---------------------------------------------
 def test_ex_dot_dispatch_literals():
-    q = np.ones(960, np.float32)
-    c2 = np.full(960, 2, np.uint16); p2 = np.zeros(240, np.uint8)
-    B().rbq_build_pack_ex_code_2bit(c2.ctypes.data, p2.ctypes.data, 960)
-    assert abs(L().ref_ex_dot(q.ctypes.data, p2.ctypes.data, 960, 2) - 1920.0) < 1e-3
-    c6 = np.full(960, 10, np.uint16); p6 = np.zeros(720, np.uint8)
-    B().rbq_build_pack_ex_code_6bit(c6.ctypes.data, p6.ctypes.data, 960)
-    assert abs(L().ref_ex_dot(q.ctypes.data, p6.ctypes.data, 960, 6) - 9600.0) < 1e-3
-    assert L().ref_ex_dot(q.ctypes.data, p6.ctypes.data, 960, 0) == 0.0
+    k = KATS["ex_dot_dispatch"]
+    dim = k["dim"]
+    q = np.full(dim, k["query_all"], np.float32)
+    for case in k["cases"]:
+        ex = case["ex_bits"]
+        codes = np.full(dim, case["codes_all"], np.uint16)
+        pk = np.zeros(dim * 6 // 8, np.uint8)
+        if ex == 2:
+            B().rbq_build_pack_ex_code_2bit(codes.ctypes.data, pk.ctypes.data, dim)
+        else:
+            B().rbq_build_pack_ex_code_6bit(codes.ctypes.data, pk.ctypes.data, dim)
+        assert abs(L().ref_ex_dot(q.ctypes.data, pk.ctypes.data, dim, ex) - case["sum"]) < k["tolerance"]
     # ex_bits=1 is rejected (select_excode_ipfunc panics, src/simd.rs:3210): the builder refuses 2-bit totals
     x = make_dataset(64, 32, 2, 0)
     with pytest.raises(rq.RabitqError):
@@ -103,18 +113,20 @@ def test_ex_dot_ramp_vs_unpacked():
 
 # ---- accumulate known answer (src/simd.rs:2279-2342): bits {0,3,8,15}, sum == 100 -------------------------
 def test_scalar_accumulate_known_answer_and_formulations_agree():
-    dim = 64
-    bits = np.zeros(dim, np.uint8); bits[[0, 3, 8, 15]] = 1
+    k = KATS["scalar_accumulate"]
+    dim = k["dim"]
+    bits = np.zeros(dim, np.uint8); bits[k["set_bits"]] = 1
     packed = _pack_bits(bits)
     fs = np.zeros(32 * dim // 8, np.uint8)
     B().rbq_build_pack_codes(packed.ctypes.data, 1, dim // 8, fs.ctypes.data)
     lut = np.zeros(dim * 4, np.uint8)
-    lut[9] = 10; lut[16] = 20; lut[2 * 16 + 8] = 30; lut[3 * 16 + 1] = 40
+    for pos, val in k["lut_entries"].items():  # lut[9]=10, lut[16]=20, lut[2*16+8]=30, lut[3*16+1]=40
+        lut[int(pos)] = val
     for fn in ("ref_accumulate_batch_scalar", "ref_accumulate_batch_shuffle_emul", "ref_accumulate_batch"):
         res = np.zeros(32, np.uint16)
         getattr(L(), fn)(fs.ctypes.data, lut.ctypes.data, dim, res.ctypes.data)
         # the 31 zero-padded vectors have code 0 everywhere and pick up lut[16] = 20 only
-        assert res[0] == 100 and (res[1:] == 20).all(), fn
+        assert res[0] == k["sum_vector0"] and (res[1:] == 20).all(), fn
 
 
 @pytest.mark.parametrize("D", [64, 128, 960, 1536])
@@ -170,8 +182,10 @@ def test_lut_accumulate_vs_direct_dot():
 
 # ---- rotation (src/rotation.rs:613-676; src/tests.rs:1786-1795) ---------------------------------------------
 def test_rotation_properties():
-    assert L().ref_floor_log2(960) == 9 and L().ref_floor_log2(1) == 0 and L().ref_floor_log2(1024) == 10
-    assert L().ref_padded_dim(64, 1) == 64 and L().ref_padded_dim(960, 1) == 960 and L().ref_padded_dim(100, 1) == 128
+    for x, want in KATS["rotation"]["floor_log2"].items():
+        assert L().ref_floor_log2(int(x)) == want
+    for x, want in KATS["rotation"]["padded_dim_fht"].items():
+        assert L().ref_padded_dim(int(x), 1) == want
     x = np.arange(16, dtype=np.float32)
     y = x.copy()
     L().ref_fht(y.ctypes.data, 16); L().ref_fht(y.ctypes.data, 16)
@@ -294,3 +308,18 @@ def test_mstg_posting_scan_oracle_properties():
     rc, iids, isc, icnt, _ = oracle.search_batch(built, q, 5, 16)
     pos = isc > 0  # the IVF path does not clamp
     assert np.array_equal(np.sort(sc2[pos]), np.sort(isc[pos]))
+
+
+# ---- committed vectors of this repository's own oracle (tests/golden/oracle_vectors.npz) ----------------------
+def test_oracle_matches_committed_vectors():
+    """Seeded inputs -> the arrays tests/golden/make_oracle_vectors.py recorded (rotation, LUT, ids, scores,
+    counts, diagnostics): any change of the oracle's or the CPU builder's arithmetic shows up here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.join(GOLDEN, "make_oracle_vectors.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    want = np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+    for name, *cfg in gen.CASES:
+        _, _, got = gen.run_case(*cfg)
+        for k, v in got.items():
+            w = want[f"{name}/{k}"]
+            assert v.shape == w.shape and np.array_equal(v.view(np.uint8), w.view(np.uint8)), f"{name}/{k}"
