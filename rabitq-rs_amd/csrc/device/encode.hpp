@@ -82,8 +82,6 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
     const uint32_t src = (slot < P.nslots) ? P.slot_src[slot] : kNoSrc;
     const bool valid = src != kNoSrc;
     const uint32_t D = P.D, Dc = P.Dc, ex_bits = P.ex_bits;
-    const uint32_t list = has_blk ? P.block_list[blk] : 0u;
-    const float* crow = P.centroids + (size_t)list * D;
     const size_t stride = (size_t)Dc * 4 + 384;
     uint8_t* rec = P.blocks + (size_t)blk * stride;
     const float F32_EPS = 1.1920929e-07f, K_CONST_EPSILON = 1.9f;
@@ -108,7 +106,6 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
         __syncthreads();
         return w;
     };
-    (void)crow;
 
     // ---- pass A: residual, sign bits, |r|^2 chain, the five dots of compute_one_bit_factors
     float n2 = -0.0f;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)cap2 * 8);
     uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
     __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_mask, s_k, s_cnt, s_bad;
+    __shared__ uint32_t s_k, s_cnt, s_bad;
     __shared__ unsigned long long s_nvec;
 #ifdef RBQ_SEL_STAMPS
     unsigned long long ts[8]; int tn = 0;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     };
 
     for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
-    if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
+    if (tid == 0) { s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
     __syncthreads();
 
     SSTAMP(); // 1: row + query staged
