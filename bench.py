@@ -240,7 +240,9 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    idx.profile_begin()  # HIP events on the kernels' own stream; no host sync inside the timed region
+    # HIP events on the kernels' own stream, no host sync inside the timed region.  Only the roofline kernel is
+    # timed here (two event records per launch); the other stages are timed in the single-stream pass below.
+    idx.profile_begin(stages=("scan",))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -269,7 +271,7 @@ def main():
                                 d_sc[0].data_ptr(), d_cnt[0].data_ptr(), stream=streams[0].cuda_stream)
 
     serial = None
-    if ns > 1:
+    if True:
         for _ in range(2):
             step1()
         fence()
@@ -365,7 +367,7 @@ def main():
                    "parallelism": f"index replicated x{world}, queries sharded, RCCL all_gather of top-k",
                    "streams": ns},
         "recall_at_10": recall,
-        "stage_ms": {k: round(v[0], 4) for k, v in stage_ms.items()},
+        "stage_ms": serial["stage_ms"],  # every stage alone on one stream (the timed region only times k_scan)
         "index_build_s": round(t_build, 1),
         "encoder": encoder,
         "rank_fallbacks": int(idx.rank_fallbacks()),

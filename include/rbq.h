@@ -177,6 +177,10 @@ double rbq_profile_stage_ms(const rbq_index* idx, const char* stage, uint64_t* l
 /* Algorithmic bytes (sum over probed lists of n_c*(D/8+12)) of the
  * scan launches between rbq_profile_begin/end. */
 uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
+/* Which stages rbq_profile_begin/end time: bit 0 prep, 1 rank, 2 select, 3 scan (default: all four). Every timed
+ * stage costs two event records per launch; a throughput measurement that only needs the dominant kernel's
+ * duration selects that stage alone. */
+void rbq_profile_select_stages(rbq_index* idx, uint32_t mask);
 /* Number of queries (since creation) whose probe selection fell back from the MFMA shortlist to the
  * all-lists canonical ranking (shortlist overflow / non-finite scores). Diagnostic. */
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);

@@ -72,9 +72,25 @@ struct Workspace {
 };
 
 struct StageProf {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; // pairs recorded since rbq_profile_begin
     double ms = 0;
     uint64_t launches = 0;
+};
+// Event pairs are created once and recycled: hipEventCreate inside the launch path cost ~15 % of the
+// overlapped throughput and broke down beyond three caller streams.
+struct EventPool {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_pairs;
+    bool take(std::pair<hipEvent_t, hipEvent_t>& p) {
+        if (!free_pairs.empty()) { p = free_pairs.back(); free_pairs.pop_back(); return true; }
+        if (hipEventCreate(&p.first) != hipSuccess) return false;
+        if (hipEventCreate(&p.second) != hipSuccess) { (void)hipEventDestroy(p.first); return false; }
+        return true;
+    }
+    void give(const std::pair<hipEvent_t, hipEvent_t>& p) { free_pairs.push_back(p); }
+    void destroy() {
+        for (auto& e : free_pairs) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        free_pairs.clear();
+    }
 };
 
 } // namespace
@@ -105,7 +121,9 @@ struct rbq_index {
     std::map<hipStream_t, Workspace*> stream_ws; // rbq_search_batch_device: one workspace per caller stream
     // profiling
     bool profiling = false;
+    uint32_t prof_mask = 0xf; // stages that are timed while `profiling` (bit s = stage s)
     StageProf prof[4]; // prep, rank, select, scan
+    EventPool ev_pool;
     uint64_t prof_scan_bytes = 0;
 };
 
@@ -121,6 +139,7 @@ void free_index(rbq_index* ix) {
     for (auto& kv : ix->stream_ws) { kv.second->release(); delete kv.second; }
     for (auto& sp : ix->prof)
         for (auto& e : sp.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    ix->ev_pool.destroy();
     delete ix;
 }
 
@@ -521,18 +540,22 @@ void give_ws(rbq_index* ix, Workspace* w) {
 }
 
 struct ProfScope {
-    rbq_index* ix; int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    rbq_index* ix; int stage; hipStream_t s; std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    bool on = false;
     ProfScope(rbq_index* ix_, int st, hipStream_t s_) : ix(ix_), stage(st), s(s_) {
-        if (ix->profiling) {
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            (void)hipEventRecord(a, s);
+        if (ix->profiling && ((ix->prof_mask >> st) & 1u)) {
+            {
+                std::lock_guard<std::mutex> g(ix->mu);
+                on = ix->ev_pool.take(ev);
+            }
+            if (on) (void)hipEventRecord(ev.first, s);
         }
     }
     ~ProfScope() {
-        if (ix->profiling && a) {
-            (void)hipEventRecord(b, s);
+        if (on) {
+            (void)hipEventRecord(ev.second, s);
             std::lock_guard<std::mutex> g(ix->mu);
-            ix->prof[stage].ev.emplace_back(a, b);
+            ix->prof[stage].ev.push_back(ev);
         }
     }
 };
@@ -1073,7 +1096,7 @@ void rbq_profile_begin(rbq_index* ix) {
     if (!ix) return;
     std::lock_guard<std::mutex> g(ix->mu);
     for (auto& sp : ix->prof) {
-        for (auto& e : sp.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        for (auto& e : sp.ev) ix->ev_pool.give(e);
         sp.ev.clear(); sp.ms = 0; sp.launches = 0;
     }
     ix->prof_scan_bytes = 0;
@@ -1096,7 +1119,7 @@ void rbq_profile_end(rbq_index* ix) {
         for (auto& e : sp.ev) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sp.ms += ms; sp.launches++; }
-            (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+            ix->ev_pool.give(e);
         }
         sp.ev.clear();
     }
@@ -1109,6 +1132,7 @@ double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* la
     return ix->prof[s].launches ? ix->prof[s].ms / (double)ix->prof[s].launches : 0.0;
 }
 uint64_t rbq_profile_scan_bytes(const rbq_index* ix) { return ix ? ix->prof_scan_bytes : 0; }
+void rbq_profile_select_stages(rbq_index* ix, uint32_t mask) { if (ix) ix->prof_mask = mask & 0xfu; }
 int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
     if (!ix || !name) return RBQ_INVALID_CONFIG;
     if (!std::strcmp(name, "block_bound")) { ix->no_block_bound = value == 0; return RBQ_OK; }
