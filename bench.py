@@ -245,7 +245,7 @@ def main():
     fence()
     # HIP events on the kernels' own stream, no host sync inside the timed region.  Only the roofline kernel is
     # timed here (two event records per launch); the other stages are timed in the single-stream pass below.
-    idx.profile_begin(stages=("scan",))
+    idx.profile_begin(stages=("scan",), every=int(os.environ.get("RBQ_BENCH_TAP_EVERY", "1")))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()

@@ -181,6 +181,8 @@ uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
  * stage costs two event records per launch; a throughput measurement that only needs the dominant kernel's
  * duration selects that stage alone. */
 void rbq_profile_select_stages(rbq_index* idx, uint32_t mask);
+/* Time only every n-th launch of each selected stage (default 1 = every launch). */
+void rbq_profile_set_sampling(rbq_index* idx, uint32_t every);
 /* Number of queries (since creation) whose probe selection fell back from the MFMA shortlist to the
  * all-lists canonical ranking (shortlist overflow / non-finite scores). Diagnostic. */
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);

@@ -122,6 +122,8 @@ struct rbq_index {
     // profiling
     bool profiling = false;
     uint32_t prof_mask = 0xf; // stages that are timed while `profiling` (bit s = stage s)
+    uint32_t prof_every = 1;  // time every n-th launch of a stage
+    uint32_t prof_seq[4] = {0, 0, 0, 0};
     StageProf prof[4]; // prep, rank, select, scan
     EventPool ev_pool;
     uint64_t prof_scan_bytes = 0;
@@ -546,7 +548,7 @@ struct ProfScope {
         if (ix->profiling && ((ix->prof_mask >> st) & 1u)) {
             {
                 std::lock_guard<std::mutex> g(ix->mu);
-                on = ix->ev_pool.take(ev);
+                if (ix->prof_seq[st]++ % ix->prof_every == 0) on = ix->ev_pool.take(ev);
             }
             if (on) (void)hipEventRecord(ev.first, s);
         }
@@ -1133,6 +1135,7 @@ double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* la
 }
 uint64_t rbq_profile_scan_bytes(const rbq_index* ix) { return ix ? ix->prof_scan_bytes : 0; }
 void rbq_profile_select_stages(rbq_index* ix, uint32_t mask) { if (ix) ix->prof_mask = mask & 0xfu; }
+void rbq_profile_set_sampling(rbq_index* ix, uint32_t every) { if (ix) ix->prof_every = every ? every : 1u; }
 int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
     if (!ix || !name) return RBQ_INVALID_CONFIG;
     if (!std::strcmp(name, "block_bound")) { ix->no_block_bound = value == 0; return RBQ_OK; }

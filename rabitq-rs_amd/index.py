@@ -52,6 +52,8 @@ def lib():
         L.rbq_index_build_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_int, vp]
         L.rbq_debug_copy_index.restype = C.c_int
         L.rbq_debug_copy_index.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
+        L.rbq_profile_set_sampling.restype = None
+        L.rbq_profile_set_sampling.argtypes = [vp, C.c_uint32]
         L.rbq_profile_select_stages.restype = None
         L.rbq_profile_select_stages.argtypes = [vp, C.c_uint32]
         L.rbq_debug_copy_workspace.restype = C.c_int
@@ -230,9 +232,10 @@ class IvfRabitqIndex:
         _check(lib().rbq_search_batch_device(self._h, d_queries, nq, query_dim, top_k, nprobe, d_filter,
                                              filter_nbits, d_ids, d_scores, d_counts, d_diag, stream))
 
-    def profile_begin(self, stages=("prep", "rank", "select", "scan")):
+    def profile_begin(self, stages=("prep", "rank", "select", "scan"), every=1):
         mask = sum(1 << ("prep", "rank", "select", "scan").index(s) for s in stages)
         lib().rbq_profile_select_stages(self._h, mask)
+        lib().rbq_profile_set_sampling(self._h, every)
         lib().rbq_profile_begin(self._h)
 
     def profile_end(self):
