@@ -454,3 +454,23 @@ def test_gpu_matches_committed_vectors():
         ok = np.isfinite(w)
         np.testing.assert_allclose(sc[ok], w[ok], rtol=RTOL, atol=0)
         idx.close()
+
+
+@pytest.mark.parametrize("nprobe", [300, 600, 800])
+def test_large_nprobe_select_paths(nprobe):
+    """nprobe > 256: more than one probe per selector thread, 1024/2048-entry shortlist windows (bitonic sort
+    instead of the rank sort), staged probe geometry of several KB; nprobe == nlist takes the all-lists branch."""
+    import torch
+    nlist, dim = 800, 64
+    n = 12 * nlist
+    data = make_dataset(n, dim, 64, 61)
+    rng = np.random.default_rng(62)
+    cent = data[rng.choice(n, nlist, replace=False)].copy()
+    x, c = torch.from_numpy(data).cuda(), torch.from_numpy(cent).cuda()
+    assign = torch.cdist(x, c).argmin(dim=1).cpu().numpy().astype(np.uint32)
+    built = rq.builder.train_with_clusters(data, cent, assign, 7, 0, 1, 63, True)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(24, dim, 64, 64)
+    _compare(built, idx, q, 10, nprobe)
+    assert idx.rank_fallbacks() == 0
+    idx.close()
