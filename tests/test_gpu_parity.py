@@ -474,3 +474,14 @@ def test_large_nprobe_select_paths(nprobe):
     _compare(built, idx, q, 10, nprobe)
     assert idx.rank_fallbacks() == 0
     idx.close()
+
+
+@pytest.mark.parametrize("top_k", [63, 64, 500, 4096])
+def test_large_top_k(top_k):
+    """top_k < 64 keeps the heap in registers, top_k >= 64 in LDS (exact BinaryHeap emulation, one lane); 4096 is the
+    documented limit and exceeds the number of probed candidates here (counts < top_k, NaN / u64::MAX padding)."""
+    data, built = build_index(n=6000, dim=64, nlist=24, total_bits=7, seed=71)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(12, 64, 6, 72)
+    _compare(built, idx, q, top_k, 8)
+    idx.close()
