@@ -485,3 +485,25 @@ def test_large_top_k(top_k):
     q = make_dataset(12, 64, 6, 72)
     _compare(built, idx, q, top_k, 8)
     idx.close()
+
+
+def test_empty_lists_and_single_vector_lists():
+    """Lists without vectors (their probes contribute no blocks) and one-vector lists, through both builders."""
+    import torch
+    rng = np.random.default_rng(81)
+    n, dim, nlist = 3000, 64, 40
+    data = make_dataset(n, dim, 8, 82)
+    cent = data[rng.choice(n, nlist, replace=False)].copy()
+    assign = rng.integers(0, nlist, n).astype(np.uint32)
+    assign[assign % 5 == 0] = 1          # lists 0, 5, 10, ... stay empty
+    assign[assign == 7] = 1
+    assign[0] = 7                         # list 7 holds exactly one vector
+    built = rq.builder.train_with_clusters(data, cent, assign, 7, 0, 1, 83, True)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(20, dim, 8, 84)
+    _compare(built, idx, q, 10, 40)      # every list probed, the empty ones included
+    _compare(built, idx, q, 10, 9)
+    xd = torch.from_numpy(data).cuda(); ad = torch.from_numpy(assign.astype(np.int32)).cuda()
+    enc = rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ad.data_ptr(), n, built.t_const)
+    _compare(built, enc, q, 10, 40)
+    idx.close(); enc.close()
