@@ -114,11 +114,19 @@ __device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, lds_lut_ptr p) 
 #endif
 }
 
-// Register image of one vector's sign code (lane l32 of a block): Dc/128 16-byte granules + optional 8-byte tail.
+// Register image of one vector's sign code (lane l32 of a block): a ROLLING window of kCodeWin 16-byte granules
+// (+ the optional 8-byte tail).  The first window is requested with the factor rows; granule g + kCodeWin is
+// requested when granule g has been consumed, so at most kCodeWin + 1 granules are live — the full image
+// (30 registers at D = 960) made the lookup phase the register peak of the kernel.
+#ifndef RBQ_CODE_WIN
+#define RBQ_CODE_WIN 3
+#endif
+constexpr int kCodeWin = RBQ_CODE_WIN;
 template <int DT>
 struct CodeRegs {
-    static constexpr int G = (DT >> 7) ? (DT >> 7) : 1;
-    uint4 x[G];
+    static constexpr int G = DT >> 7;                         // full granules
+    static constexpr int W = G < kCodeWin ? (G ? G : 1) : kCodeWin;
+    uint4 x[W];
     uint2 tail;
 };
 
@@ -126,23 +134,27 @@ template <int DT>
 __device__ __forceinline__ void load_codes(CodeRegs<DT>& c, const uint8_t* __restrict__ blk, uint32_t l32) {
     const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
 #pragma unroll
-    for (int g = 0; g < (DT >> 7); ++g) c.x[g] = cp[g * 32];
+    for (int g = 0; g < CodeRegs<DT>::W && g < (DT >> 7); ++g) c.x[g] = cp[g * 32];
     if (DT & 64) c.tail = *(reinterpret_cast<const uint2*>(blk + (DT >> 7) * 512) + l32);
 }
 
 template <int DT>
-__device__ __forceinline__ uint32_t lookup_codes(const CodeRegs<DT>& c, lds_lut_ptr lut) {
+__device__ __forceinline__ uint32_t lookup_codes(CodeRegs<DT>& c, const uint8_t* __restrict__ blk, uint32_t l32, lds_lut_ptr lut) {
+    constexpr int G = DT >> 7, W = CodeRegs<DT>::W;
+    const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
     uint32_t acc = 0;
 #pragma unroll
-    for (int g = 0; g < (DT >> 7); ++g) {
-        look8(acc, c.x[g].x, lut + g * 512);
-        look8(acc, c.x[g].y, lut + g * 512 + 128);
-        look8(acc, c.x[g].z, lut + g * 512 + 256);
-        look8(acc, c.x[g].w, lut + g * 512 + 384);
+    for (int g = 0; g < G; ++g) {
+        const uint4 x = c.x[g % W];
+        if (g + W < G) c.x[g % W] = cp[(g + W) * 32];
+        look8(acc, x.x, lut + g * 512);
+        look8(acc, x.y, lut + g * 512 + 128);
+        look8(acc, x.z, lut + g * 512 + 256);
+        look8(acc, x.w, lut + g * 512 + 384);
     }
     if (DT & 64) {
-        look8(acc, c.tail.x, lut + (DT >> 7) * 512);
-        look8(acc, c.tail.y, lut + (DT >> 7) * 512 + 128);
+        look8(acc, c.tail.x, lut + G * 512);
+        look8(acc, c.tail.y, lut + G * 512 + 128);
     }
     return acc;
 }
@@ -663,7 +675,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #endif
             if (live_c) { // wave-uniform
                 STAMP(st_a);
-                const uint32_t accu = (DT ? lookup_codes<DT>(cc, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
+                const uint32_t accu = (DT ? lookup_codes<DT>(cc, blk, l32, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
 #ifdef RBQ_STAMPS
                 asm volatile("" :: "v"(accu));
                 STAMP(st_b); st_look += st_b - st_a;
