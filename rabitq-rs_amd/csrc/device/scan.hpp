@@ -55,7 +55,7 @@ struct ScanParams {
 };
 
 #ifndef RBQ_SCAN_WAVES
-#define RBQ_SCAN_WAVES 4    // launch-bounds occupancy target (waves per SIMD)
+#define RBQ_SCAN_WAVES 5    // launch-bounds occupancy target (waves per SIMD): 96 VGPRs, room for a fifth wave of another kernel
 #endif
 #ifndef RBQ_NSCAN
 #define RBQ_NSCAN 3         // scanner waves per workgroup (3 + replay wave = 256 threads: 4 workgroups per CU)
@@ -119,7 +119,7 @@ __device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, lds_lut_ptr p) 
 // requested when granule g has been consumed, so at most kCodeWin + 1 granules are live — the full image
 // (30 registers at D = 960) made the lookup phase the register peak of the kernel.
 #ifndef RBQ_CODE_WIN
-#define RBQ_CODE_WIN 3
+#define RBQ_CODE_WIN 2
 #endif
 constexpr int kCodeWin = RBQ_CODE_WIN;
 template <int DT>
