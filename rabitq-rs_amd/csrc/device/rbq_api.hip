@@ -82,8 +82,10 @@ struct EventPool {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_pairs;
     bool take(std::pair<hipEvent_t, hipEvent_t>& p) {
         if (!free_pairs.empty()) { p = free_pairs.back(); free_pairs.pop_back(); return true; }
-        if (hipEventCreate(&p.first) != hipSuccess) return false;
-        if (hipEventCreate(&p.second) != hipSuccess) { (void)hipEventDestroy(p.first); return false; }
+        // timing only: without the system-scope fence a default event performs when it completes (that fence sits
+        // between the kernels of a stream and shows up in the overlapped throughput)
+        if (hipEventCreateWithFlags(&p.first, hipEventDisableSystemFence) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&p.second, hipEventDisableSystemFence) != hipSuccess) { (void)hipEventDestroy(p.first); return false; }
         return true;
     }
     void give(const std::pair<hipEvent_t, hipEvent_t>& p) { free_pairs.push_back(p); }
