@@ -411,6 +411,9 @@ struct SortedTop { // operates on the registers of a RegHeap (only one of the tw
 #ifndef RBQ_FILL_K
 #define RBQ_FILL_K 2
 #endif
+#ifndef RBQ_REPLAY_PRIO
+#define RBQ_REPLAY_PRIO 3
+#endif
 #ifndef RBQ_WIN_GROW
 #define RBQ_WIN_GROW 4
 #endif
@@ -470,6 +473,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         for (uint32_t i = tid; i < qlen; i += kScanThreads) s_q[i] = i < D ? P.rot[(size_t)q * D + i] : 0.0f;
         if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; }
     }
+    // the replay wave is the serial part of every tile: let it issue ahead of the (many) scanner waves it shares
+    // its SIMD with
+    if (!scanner) __builtin_amdgcn_s_setprio(RBQ_REPLAY_PRIO);
     const QueryConsts qc = P.consts[q];
     const ProbeInfo* probe = P.probe + (size_t)q * P.nprobe;
     const StreamItem* wl = P.wl + (size_t)q * P.wl_stride;
@@ -793,17 +799,33 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                     bool tie = false;
                     int dk = len_s < top_k ? 0x7f800000 : __builtin_amdgcn_readlane(rh.hd, (int)RegHeap::uni(top_k - 1u));
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
+                    // The threshold only moves when an entry actually enters the run, so the entries between two
+                    // such events are resolved together: one pass of ballots per INSERTION (about a quarter of the
+                    // evaluated survivors), not per survivor.  Lane j holds taken survivor j of the stretch.
+                    const float lbv = __int_as_float(bt.v_lb), dvf = __int_as_float(v_d);
+                    const bool fin_l = (v_d & 0x7f800000) != 0x7f800000;
+                    const int kd_l = RegHeap::key(v_d);
+                    const unsigned long long fin_m = __ballot(fin_l);
+                    (void)dvf;
                     while (todo) {
-                        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
-                        todo &= todo - 1ull;
-                        const float lb = __int_as_float(__builtin_amdgcn_readlane(bt.v_lb, (int)j));
-                        if (__ballot(lb >= __int_as_float(dk)) != 0ull) { ++c_skip; continue; }
-                        ++c_ext;
+                        const unsigned long long cand = __ballot(lbv < __int_as_float(dk)) & todo; // evaluated by the reference
+                        // entries that change the run (or tie with its maximum): finite and not beyond the k-th
+                        const bool chg = fin_l && (len_s < top_k || kd_l <= RegHeap::key(dk));
+                        const unsigned long long ins = __ballot(chg) & cand;
+                        const unsigned long long before = ins ? ((1ull << __builtin_ctzll(ins)) - 1ull) : ~0ull;
+                        const unsigned long long done = todo & before; // resolved without a change of state
+                        c_skip += (uint32_t)__popcll(done & ~cand);
+                        c_ext += (uint32_t)__popcll(done & cand);
+                        c_est += (uint32_t)__popcll(done & cand & fin_m);
+                        if (!ins) break;
+                        const uint32_t j = (uint32_t)__builtin_ctzll(ins);
+                        todo &= ~((2ull << j) - 1ull);
+                        ++c_ext; ++c_est;
                         const int dbits = __builtin_amdgcn_readlane(v_d, (int)j);
-                        if ((dbits & 0x7f800000) == 0x7f800000) continue; // non-finite
-                        ++c_est;
+                        const int ke = RegHeap::key(dbits);
+                        if (len_s == top_k && ke == RegHeap::key(dk)) { tie = true; continue; } // which of the equal maxima leaves depends on the heap layout
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
-                        const int ke = RegHeap::key(dbits), k = RegHeap::key(rh.hd);
+                        const int k = RegHeap::key(rh.hd);
                         const bool in = lane < len_s;
                         tie |= __ballot(in && k == ke) != 0ull;
                         const uint32_t ipos = (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
