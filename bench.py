@@ -131,6 +131,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RBQ_BENCH_REHEARSAL"):  # several ranks on ONE GPU with gloo: exercises the N>1 control flow only
+        local = 0
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with nproc-per-node {a.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
@@ -139,7 +141,10 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("RBQ_BENCH_REHEARSAL"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if world > 1:
         a.device_build = True  # N ranks x an all-core CPU build on one host would only oversubscribe it; the
@@ -296,11 +301,11 @@ def main():
         idx.set_option("block_bound", 0)
         for _ in range(2):
             step1()
-        fence()
+        torch.cuda.synchronize(dev)  # rank 0 only: no collective in here
         idx.profile_begin()
         for _ in range(max(3, a.steps // 4)):
             step1()
-        fence()
+        torch.cuda.synchronize(dev)  # rank 0 only: no collective in here
         idx.profile_end()
         ms2, n2 = idx.profile_stage("scan")
         b2 = idx.profile_scan_bytes() / max(n2, 1)

@@ -507,3 +507,25 @@ def test_empty_lists_and_single_vector_lists():
     enc = rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ad.data_ptr(), n, built.t_const)
     _compare(built, enc, q, 10, 40)
     idx.close(); enc.close()
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 control flow (device build on every rank, barriers, per-stream gather buffers, rank-0-only
+    sections) with two ranks sharing this GPU over gloo — RCCL itself needs one GPU per rank and is left to the
+    8-GPU run; what must not happen there is a rank-0-only collective or a crash in the N > 1 branches."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RBQ_BENCH_REHEARSAL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["streams_identical"] and d["value"] > 0 and d["roofline"]["launches"] == 4
