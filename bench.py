@@ -420,6 +420,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 has extra (supplementary) work behind it: nobody tears the group down early
         dist.destroy_process_group()
 
 
