@@ -221,12 +221,14 @@ def main():
     # side streams only: with the (legacy) default stream among them, the event records of the timing taps made
     # four or more streams collapse to a quarter of the throughput on this device
     streams = [torch.cuda.Stream(dev) for _ in range(ns)]
-    d_ids = [torch.empty(a.batch, a.top_k, dtype=torch.int64, device=dev) for _ in range(ns)]  # u64 bit patterns
-    d_sc = [torch.empty(a.batch, a.top_k, dtype=torch.float32, device=dev) for _ in range(ns)]
+    # ids (u64 bit patterns) and scores of a batch live in ONE buffer, so the final exchange is a single all_gather
+    nres = a.batch * a.top_k
+    d_pack = [torch.empty(nres * 12, dtype=torch.uint8, device=dev) for _ in range(ns)]
+    d_ids = [p[:nres * 8].view(torch.int64).view(a.batch, a.top_k) for p in d_pack]
+    d_sc = [p[nres * 8:].view(torch.float32).view(a.batch, a.top_k) for p in d_pack]
     d_cnt = [torch.empty(a.batch, dtype=torch.int32, device=dev) for _ in range(ns)]
     # gather targets of the final top-k exchange: one set per stream, so overlapping batches never share a buffer
-    g_ids = [[torch.empty_like(d_ids[0]) for _ in range(world)] for _ in range(ns)] if world > 1 else None
-    g_sc = [[torch.empty_like(d_sc[0]) for _ in range(world)] for _ in range(ns)] if world > 1 else None
+    g_pack = [[torch.empty_like(d_pack[0]) for _ in range(world)] for _ in range(ns)] if world > 1 else None
     step_no = [0]
 
     def step():
@@ -236,8 +238,7 @@ def main():
                                 d_cnt[i].data_ptr(), stream=streams[i].cuda_stream)
         if world > 1:  # the path's only exchange: final top-k gather over RCCL/xGMI
             with torch.cuda.stream(streams[i]):
-                dist.all_gather(g_ids[i], d_ids[i])
-                dist.all_gather(g_sc[i], d_sc[i])
+                dist.all_gather(g_pack[i], d_pack[i])
 
     def fence():
         if world > 1:
