@@ -5,6 +5,7 @@
 // enqueue prep -> rank -> select -> scan for each query batch.  There is no CPU compute path:
 // every failure to reach the GPU surfaces as RBQ_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -545,19 +546,23 @@ void give_ws(rbq_index* ix, Workspace* w) {
 
 struct ProfScope {
     rbq_index* ix; int stage; hipStream_t s; std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    bool on = false;
-    ProfScope(rbq_index* ix_, int st, hipStream_t s_) : ix(ix_), stage(st), s(s_) {
+    bool on = false, ext = false;
+    // ext: the launch itself carries the event pair (hipExtLaunchKernelGGL: start/stop come from the dispatch
+    // packet, no separate marker packets in the queue); otherwise the pair is recorded around the scope
+    ProfScope(rbq_index* ix_, int st, hipStream_t s_, bool ext_ = false) : ix(ix_), stage(st), s(s_), ext(ext_) {
         if (ix->profiling && ((ix->prof_mask >> st) & 1u)) {
             {
                 std::lock_guard<std::mutex> g(ix->mu);
                 if (ix->prof_seq[st]++ % ix->prof_every == 0) on = ix->ev_pool.take(ev);
             }
-            if (on) (void)hipEventRecord(ev.first, s);
+            if (on && !ext) (void)hipEventRecord(ev.first, s);
         }
     }
+    hipEvent_t start() const { return on && ext ? ev.first : nullptr; }
+    hipEvent_t stop() const { return on && ext ? ev.second : nullptr; }
     ~ProfScope() {
         if (on) {
-            (void)hipEventRecord(ev.second, s);
+            if (!ext) (void)hipEventRecord(ev.second, s);
             std::lock_guard<std::mutex> g(ix->mu);
             ix->prof[stage].ev.push_back(ev);
         }
@@ -565,21 +570,22 @@ struct ProfScope {
 };
 
 template <int DT, int EX>
-hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s) {
+hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (lds > 48 * 1024) { // default dynamic-LDS limit covers the common case; raising it is a driver call
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
+    if (ev0) hipExtLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, ev0, ev1, 0, P);
+    else hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
     return hipGetLastError();
 }
 template <int DT>
-hipError_t launch_scan(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s) {
-    if (DT == 0) return launch_scan_t<0, 0>(P, nq, lds, s);
+hipError_t launch_scan(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (DT == 0) return launch_scan_t<0, 0>(P, nq, lds, s, ev0, ev1);
     switch (P.ex_bits) {
-        case 0: return launch_scan_t<DT, 0>(P, nq, lds, s);
-        case 2: return launch_scan_t<DT, 2>(P, nq, lds, s);
-        default: return launch_scan_t<DT, 6>(P, nq, lds, s);
+        case 0: return launch_scan_t<DT, 0>(P, nq, lds, s, ev0, ev1);
+        case 2: return launch_scan_t<DT, 2>(P, nq, lds, s, ev0, ev1);
+        default: return launch_scan_t<DT, 6>(P, nq, lds, s, ev0, ev1);
     }
 }
 
@@ -588,7 +594,7 @@ int scan_stage(rbq_index* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, 
                const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
                rbq_diag* d_diag, bool mstg, hipStream_t stream) {
     const uint32_t D = ix->D, Dc = ix->Dc;
-    ProfScope ps(ix, 3, stream);
+    ProfScope ps(ix, 3, stream, /*ext=*/true);
     ScanParams P;
     P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
     P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
@@ -604,10 +610,10 @@ int scan_stage(rbq_index* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, 
     P.mstg = mstg ? 1u : 0u;
     const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, top_k);
     hipError_t e;
-    if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream);
-    else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream);
-    else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream);
-    else e = launch_scan<0>(P, (uint32_t)nq, lds, stream);
+    if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
+    else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
+    else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
+    else e = launch_scan<0>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
     HIP_TRY(e);
     return RBQ_OK;
 }
