@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16(const uint16_t* __re
                 for (int b = 0; b < TN; ++b) {
                     // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used.  With it in this GEMM, the
                     // workgroup-per-query k_prep of a NEIGHBOURING stream computed wrong LUT bytes (one 16-lane pass
-                    // of a quantisation result at a time, tools/stress3.py) although neither kernel writes outside
+                    // of a quantisation result at a time, tests/diag/stress3.py) although neither kernel writes outside
                     // its own buffers; the K=8 form below never showed it, nor does k_prep_wave with either form,
                     // and a stand-alone MFMA-beside-division test (tools/repro/) stays clean.  Root cause not
                     // established; the combination that ships is the one every stress run has been clean with

@@ -1,11 +1,12 @@
 """Diagnostic: repeat one full-size batch many times and compare every run with the oracle (ids exact)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
 import rabitq_rs_amd as rq
-from oracle import oracle
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle
 a = bench.parse()
 reps = int(os.environ.get("STRESS_REPS", "30"))
 dev = torch.device("cuda", 0)

@@ -1,12 +1,13 @@
 """Diagnostic: a 'victim' index on one stream and a 'noise' index on other streams; which combination of options
 on either side makes the victim's results deviate from the oracle?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
 import rabitq_rs_amd as rq
-from oracle import oracle
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle
 a = bench.parse()
 reps = int(os.environ.get("STRESS_REPS", "6"))
 dev = torch.device("cuda", 0)

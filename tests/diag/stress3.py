@@ -1,6 +1,6 @@
 """Diagnostic: which intermediate buffer of a victim stream differs between a quiet run and a run beside noise streams?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
