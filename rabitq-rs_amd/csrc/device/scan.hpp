@@ -77,8 +77,8 @@ constexpr uint32_t kBatchDone = 0xffffffffu;
 // Lane l holds the codes of dims 16t+l (t = 0..D/16-1); unit j packs codes t = j*CPU .. j*CPU+CPU-1 as a
 // little-endian 128-bit string, ex bits each, with no code straddling two units (CPU = 128/ex: 21 for 6-bit,
 // 64 for 2-bit).  Unused code slots are zero.
-__host__ __device__ inline uint32_t ex_cpu(uint32_t ex_bits) { return ex_bits ? 128u / ex_bits : 1u; }
-__host__ __device__ inline uint32_t ex_w4(uint32_t D, uint32_t ex_bits) { // 16-byte units per lane
+__host__ __device__ constexpr uint32_t ex_cpu(uint32_t ex_bits) { return ex_bits ? 128u / ex_bits : 1u; }
+__host__ __device__ constexpr uint32_t ex_w4(uint32_t D, uint32_t ex_bits) { // 16-byte units per lane
     return ex_bits ? (D / 16 + ex_cpu(ex_bits) - 1) / ex_cpu(ex_bits) : 0u;
 }
 __host__ __device__ inline uint32_t ex_bytes_dev(uint32_t D, uint32_t ex_bits) { return ex_w4(D, ex_bits) * 256u; }
@@ -313,6 +313,33 @@ __device__ __forceinline__ float ex_dot_all(const uint4 (&u)[kExRegUnits], const
     }
     return sacc;
 }
+// Two vectors at once: every query value is read from LDS once and feeds two independent FMA chains in the
+// reference's order (used when a vector's ex codes fit ONE 128-bit unit per lane, i.e. small dimensions, where a
+// refine round is pure memory latency and twice the survivors per round halve the rounds).
+template <int EX>
+__device__ __forceinline__ void ex_dot_pair1(const uint4& u0, const uint4& u1, const float* sq, uint32_t gl, uint32_t ncodes,
+                                             float& s0, float& s1) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    const uint32_t w0[5] = {u0.x, u0.y, u0.z, u0.w, 0u}, w1[5] = {u1.x, u1.y, u1.z, u1.w, 0u};
+    const float* qj = sq + gl;
+    s0 = 0.0f; s1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CPU; ++k) {
+        if ((uint32_t)k < ncodes) { // wave-uniform: D/16 codes per lane
+            const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+            uint32_t c0, c1;
+            if (sh + EX <= 32) { c0 = (w0[idx] >> sh) & mask; c1 = (w1[idx] >> sh) & mask; }
+            else {
+                c0 = ((w0[idx] >> sh) | (w0[idx + 1] << (32 - sh))) & mask;
+                c1 = ((w1[idx] >> sh) | (w1[idx + 1] << (32 - sh))) & mask;
+            }
+            const float qv = qj[16 * k];
+            s0 = fmaf((float)c0, qv, s0);
+            s1 = fmaf((float)c1, qv, s1);
+        }
+    }
+}
 __device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_add_ps halving tree
     sacc = sacc + __shfl_xor(sacc, 8, 16);
     sacc = sacc + __shfl_xor(sacc, 4, 16);
@@ -423,7 +450,7 @@ constexpr int kQueueCap = 512;                    // live-block FIFO (>= kTileBl
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 __host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
     return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 4;
+           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 8;
 }
 
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
@@ -452,7 +479,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t* s_nskip = s_misc + 2;
     uint32_t& s_nbatch = *(s_misc + 3);   // refine batch size of the current round (kBatchDone = tile finished)
     uint32_t& s_restart = *(s_misc + 4);  // a distance tie was met on the sorted fast path: re-run with the exact heap
-    uint32_t* s_batch = s_misc + 8;       // [kScanThreads/16] queue positions to refine in this round
+    uint32_t* s_batch = s_misc + 8;       // [2*kScanThreads/16] queue positions to refine in this round
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u, half = lane >> 5, l32 = lane & 31u;
@@ -514,6 +541,45 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 const float a = fa + q_gadd[e];
                 const float m = fr * tt2;
                 q_d[e] = a + m;
+            }
+        }
+    };
+
+    // small dimensions (one code unit per lane): group `g` of `ng` refines the survivors at queue positions
+    // s_batch[g] and s_batch[g + ng] in one pass
+    constexpr bool kDual = DT != 0 && EX != 0 && ex_w4((uint32_t)(DT ? DT : 16), (uint32_t)(EX ? EX : 2)) == 1u;
+    auto refine_pair = [&](uint32_t buf, uint32_t nb, uint32_t g, uint32_t ng) {
+        const uint32_t gl = tid & 15u;
+        if (g >= nb) return;
+        const bool has1 = g + ng < nb;
+        const uint32_t e0 = buf * kTileCand + s_batch[g];
+        const uint32_t e1 = buf * kTileCand + s_batch[has1 ? g + ng : g];
+        const uint32_t sl0 = q_slot[e0], sl1 = q_slot[e1];
+        const uint4 u0 = *(reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl0 * exb) + gl);
+        const uint4 u1 = *(reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl1 * exb) + gl);
+        float fa0 = P.f_add_ex[sl0], fr0 = P.f_rescale_ex[sl0], fa1 = P.f_add_ex[sl1], fr1 = P.f_rescale_ex[sl1];
+        asm volatile("" : "+v"(fa0), "+v"(fr0), "+v"(fa1), "+v"(fr1)); // issue the loads here
+        float sa, sb;
+        if (EX == 6) ex_dot_pair1<6>(u0, u1, s_q, gl, D / 16, sa, sb);
+        else ex_dot_pair1<(EX ? EX : 2)>(u0, u1, s_q, gl, D / 16, sa, sb);
+        sa = group16_reduce(sa);
+        sb = group16_reduce(sb);
+        if (gl == 0) {
+            {
+                float tt2 = qc.scale * q_ip[e0];
+                tt2 = tt2 + sa;
+                tt2 = tt2 + qc.kbx;
+                const float a = fa0 + q_gadd[e0];
+                const float m = fr0 * tt2;
+                q_d[e0] = a + m;
+            }
+            if (has1) {
+                float tt2 = qc.scale * q_ip[e1];
+                tt2 = tt2 + sb;
+                tt2 = tt2 + qc.kbx;
+                const float a = fa1 + q_gadd[e1];
+                const float m = fr1 * tt2;
+                q_d[e1] = a + m;
             }
         }
     };
@@ -728,7 +794,8 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #ifdef RBQ_STAMPS
                     ++st_rounds;
 #endif
-                    refine_batch(buf, nb, tid >> 4);
+                    if (kDual) refine_pair(buf, nb & 0xffffu, tid >> 4, nb >> 16);
+                    else refine_batch(buf, nb & 0xffffu, tid >> 4);
                     lds_barrier(); // C_r: refined distances visible to the replay wave
                 }
 #ifdef RBQ_STAMPS
@@ -875,13 +942,14 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             };
             if (!(heavy && ex_bits)) {
                 // light tile (or no ex codes): the wave refines with its own 4 groups while the scanners go on
-                const uint32_t G = ex_bits ? 4u : 64u;
+                const uint32_t G = ex_bits ? (kDual ? 8u : 4u) : 64u;
                 uint32_t p = 0;
                 while (p < S) {
                     const Batch bt = collect(p, G, cur_distk());
                     if (ex_bits && bt.ncol) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        refine_batch(buf, bt.ncol, lane >> 4);
+                        if (kDual) refine_pair(buf, bt.ncol, lane >> 4, 4u);
+                        else refine_batch(buf, bt.ncol, lane >> 4);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     }
                     replay(bt);
@@ -893,16 +961,18 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                 // 12 groups refine batch r+1 — collected with the threshold as it stands BEFORE batch r is
                 // replayed, i.e. a superset again — while this wave replays batch r.
                 STAMP(r0);
-                Batch cur = collect(0, (uint32_t)(kScanThreads / 16), cur_distk());
+                constexpr uint32_t kPer = kDual ? 2u : 1u; // survivors per 16-lane group and round
+                Batch cur = collect(0, kPer * (uint32_t)(kScanThreads / 16), cur_distk());
                 RSTAMP(rp_collect);
-                if (lane == 0) s_nbatch = cur.ncol;
+                if (lane == 0) s_nbatch = cur.ncol | ((uint32_t)(kScanThreads / 16) << 16); // batch size | groups
                 lds_barrier(); // B_0
-                refine_batch(buf, cur.ncol, tid >> 4);
+                if (kDual) refine_pair(buf, cur.ncol, tid >> 4, (uint32_t)(kScanThreads / 16));
+                else refine_batch(buf, cur.ncol, tid >> 4);
                 lds_barrier(); // C_0
                 RSTAMP(rp_ref0);
                 while (cur.np < S) {
-                    const Batch nxt = collect(cur.np, (uint32_t)(kNScan * 4), cur_distk());
-                    if (lane == 0) s_nbatch = nxt.ncol;
+                    const Batch nxt = collect(cur.np, kPer * (uint32_t)(kNScan * 4), cur_distk());
+                    if (lane == 0) s_nbatch = nxt.ncol | ((uint32_t)(kNScan * 4) << 16);
                     lds_barrier(); // B_r: the scanners start on batch r+1
                     RSTAMP(rp_collect);
                     replay(cur);
