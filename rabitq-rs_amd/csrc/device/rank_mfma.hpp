@@ -301,6 +301,48 @@ __device__ __forceinline__ float canon_pair2(const float* qrot, const float* __r
     return sum;
 }
 
+// Inner-product metric: the canonical dot (the score) and the canonical squared distance (g_error needs it for
+// every probed list) of one (query, list) pair in ONE pass over the centroid row; same accumulators, same order
+// as canon_pair2<1> and canon_pair2<0>.
+__device__ __forceinline__ void canon_pair2_ip_l2(const float* qrot, const float* __restrict__ c, uint32_t D, uint32_t h,
+                                                  float& dot, float& l2) {
+    const uint32_t Dmain = D & ~7u;
+    float a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (uint32_t i = 4 * h; i < Dmain; i += 8) {
+        const float4 cv = *reinterpret_cast<const float4*>(c + i);
+        const float4 qv = *reinterpret_cast<const float4*>(qrot + i);
+        const float q4[4] = {qv.x, qv.y, qv.z, qv.w}, c4[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float p = q4[k] * c4[k];
+            const float d = q4[k] - c4[k];
+            const float r = d * d;
+            a[k] = a[k] + p;
+            b[k] = b[k] + r;
+        }
+    }
+    float s0 = 0.0f, s1 = 0.0f;
+    if (Dmain) {
+        s0 = -0.0f; s1 = -0.0f;
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s0 = s0 + __shfl(a[k], l, 2);
+                s1 = s1 + __shfl(b[k], l, 2);
+            }
+    }
+    for (uint32_t i = Dmain; i < D; ++i) {
+        const float p = qrot[i] * c[i];
+        const float d = qrot[i] - c[i];
+        const float r = d * d;
+        s0 = s0 + p;
+        s1 = s1 + r;
+    }
+    dot = s0; l2 = s1;
+}
+
 // dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when RM == 1) |
 //              pgeo[4][nprobe] u32 (only when `stage`: g_add, g_err, first block, vector count of every probe)
 // RM: where the query's row of approximate scores lives during the selection passes — 2: in registers (nlist <=
@@ -491,7 +533,12 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
             if (i < n) {
                 cid = (uint32_t)keys[i];
                 const float* c = cent + (size_t)cid * D;
-                s = metric == 0 ? canon_pair2<0>(qrot, c, D, l2) : canon_pair2<1>(qrot, c, D, l2);
+                if (metric == 0) s = canon_pair2<0>(qrot, c, D, l2);
+                else {
+                    float dl2;
+                    canon_pair2_ip_l2(qrot, c, D, l2, s, dl2);
+                    if (l2 == 0) grow[cid] = dl2; // the approximate row is not needed any more: park the distances there
+                }
             }
             if (i < n && l2 == 0) keys[i] = make_key(s, cid, metric);
         }
@@ -599,7 +646,16 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
     // IP needs the canonical centroid distance of every probed list as well (g_error): computed by the same
     // 2-lane groups, 128 lists per round, and parked in the (now free) tail of the key buffer.
     float* dist_ip = reinterpret_cast<float*>(keys + nprobe); // cap2 >= 2*nprobe: room for nprobe floats
-    if (metric == 1) {
+    if (metric == 1 && !fallback) {
+        // the shortlist pass left the canonical squared distance of every shortlisted list in the score row
+        __threadfence_block();
+        __syncthreads();
+        const volatile float* vrow = grow; // written by other threads of this workgroup: read past the vector L1
+        for (uint32_t r = tid; r < nprobe; r += kThreads) {
+            dist_ip[r] = vrow[(uint32_t)(keys[r] & 0xffffffffu)]; // keys[0..nprobe) and the tail do not overlap
+        }
+        __syncthreads();
+    } else if (metric == 1) {
         for (uint32_t i0 = 0; i0 < nprobe; i0 += kThreads / 2) {
             const uint32_t r = i0 + grp;
             float d = 0.0f;
