@@ -262,6 +262,154 @@ __global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16(const uint16_t* __re
         }
 }
 
+// The same GEMM with K slabs of 32 double-buffered in LDS: slab s+1 is written (from the registers the previous
+// iteration filled) and slab s+2 requested BEFORE the MFMAs of slab s, and one barrier per slab closes the
+// iteration — the staging of the next slab runs under the matrix work of this one instead of between two barriers.
+// Rows are padded to 80 bytes (16 lanes of a ds_read_b128 group: 16 distinct 4-bank sets).  D % 32 == 0.
+// dynamic LDS: 2 x { Ah | Al [BM][80 B] | Bh | Bl [BN][80 B] }
+template <int METRIC, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16_db(const uint16_t* __restrict__ rot_hi, const uint16_t* __restrict__ rot_lo,
+                                                      const uint16_t* __restrict__ cent_hi, const uint16_t* __restrict__ cent_lo,
+                                                      const QueryConsts* __restrict__ consts,
+                                                      const float* __restrict__ cnorm2, uint32_t nq, uint32_t nlist,
+                                                      uint32_t D, float* __restrict__ scores) {
+    constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, BK = 32, LDB = BK * 2 + 16, SEG = BK / 8;
+    constexpr int NLA = BM * SEG / NT, NLB = BN * SEG / NT; // 16-byte loads per thread and array
+    constexpr int BUF = (2 * BM + 2 * BN) * LDB;
+    static_assert(BM * SEG % NT == 0 && BN * SEG % NT == 0, "tile rows must divide over the threads");
+    extern __shared__ __align__(16) unsigned char smraw[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w / WN, wn = w % WN;
+    const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const unsigned char* ga_h[NLA];
+    const unsigned char* ga_l[NLA];
+    const unsigned char* gb_h[NLB];
+    const unsigned char* gb_l[NLB];
+    uint32_t soa[NLA], sob[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const uint32_t idx = tid + (uint32_t)NT * i, row = idx / SEG, seg = idx % SEG;
+        const uint32_t ra = q0 + row < nq ? q0 + row : nq - 1u;
+        ga_h[i] = reinterpret_cast<const unsigned char*>(rot_hi) + (size_t)ra * D * 2 + seg * 16;
+        ga_l[i] = reinterpret_cast<const unsigned char*>(rot_lo) + (size_t)ra * D * 2 + seg * 16;
+        soa[i] = row * LDB + seg * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const uint32_t idx = tid + (uint32_t)NT * i, row = idx / SEG, seg = idx % SEG;
+        const uint32_t rb = c0 + row < nlist ? c0 + row : nlist - 1u;
+        gb_h[i] = reinterpret_cast<const unsigned char*>(cent_hi) + (size_t)rb * D * 2 + seg * 16;
+        gb_l[i] = reinterpret_cast<const unsigned char*>(cent_lo) + (size_t)rb * D * 2 + seg * 16;
+        sob[i] = 2 * BM * LDB + row * LDB + seg * 16;
+    }
+    u32x4 pah[NLA], pal[NLA], pbh[NLB], pbl[NLB];
+    const uint32_t nslab = D / BK;
+#define RBQ_RANK_FETCH(S)                                                                                              \
+    do {                                                                                                               \
+        const size_t ko = (size_t)(S) * BK * 2;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NLA; ++i) {                                                              \
+            pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i] + ko);                                                    \
+            pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i] + ko);                                                    \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NLB; ++i) {                                                              \
+            pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i] + ko);                                                    \
+            pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i] + ko);                                                    \
+        }                                                                                                              \
+    } while (0)
+#define RBQ_RANK_STORE(B)                                                                                              \
+    do {                                                                                                               \
+        unsigned char* base = smraw + (B) * BUF;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < NLA; ++i) {                                                              \
+            *reinterpret_cast<u32x4*>(base + soa[i]) = pah[i];                                                         \
+            *reinterpret_cast<u32x4*>(base + BM * LDB + soa[i]) = pal[i];                                              \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NLB; ++i) {                                                              \
+            *reinterpret_cast<u32x4*>(base + sob[i]) = pbh[i];                                                         \
+            *reinterpret_cast<u32x4*>(base + BN * LDB + sob[i]) = pbl[i];                                              \
+        }                                                                                                              \
+    } while (0)
+    // fragment sets of the two 16-wide K steps of a slab; A/B operand of the MFMA: lane l holds row (l & 31),
+    // k = 8 * (l >> 5) .. + 7
+    bf16x8 f0ah[TM], f0al[TM], f0bh[TN], f0bl[TN], f1ah[TM], f1al[TM], f1bh[TN], f1bl[TN];
+    const uint32_t fo = (lane & 31u) * LDB + (lane >> 5) * 16;
+#define RBQ_RANK_FRAGS(B, KC, AH, AL, BH, BL)                                                                          \
+    do {                                                                                                               \
+        const unsigned char* sAh = smraw + (B) * BUF;                                                                  \
+        const unsigned char* sBh = sAh + 2 * BM * LDB;                                                                 \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                               \
+            const uint32_t ra = (wm * 32 * TM + a * 32) * LDB + fo + (KC) * 32;                                        \
+            AH[a] = *reinterpret_cast<const bf16x8*>(sAh + ra);                                                        \
+            AL[a] = *reinterpret_cast<const bf16x8*>(sAh + BM * LDB + ra);                                             \
+        }                                                                                                              \
+        _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                               \
+            const uint32_t rb = (wn * 32 * TN + b * 32) * LDB + fo + (KC) * 32;                                        \
+            BH[b] = *reinterpret_cast<const bf16x8*>(sBh + rb);                                                        \
+            BL[b] = *reinterpret_cast<const bf16x8*>(sBh + BN * LDB + rb);                                             \
+        }                                                                                                              \
+    } while (0)
+    // K=8 MFMA form on purpose: see k_rank_bf16
+#define RBQ_RANK_MMA(AH, AL, BH, BL)                                                                                   \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a) _Pragma("unroll") for (int b = 0; b < TN; ++b) {                    \
+        acc[a][b] = mfma_x8(AL[a], BH[b], acc[a][b]);                                                                  \
+        acc[a][b] = mfma_x8(AH[a], BL[b], acc[a][b]);                                                                  \
+        acc[a][b] = mfma_x8(AH[a], BH[b], acc[a][b]);                                                                  \
+    }
+    RBQ_RANK_FETCH(0);
+    RBQ_RANK_STORE(0);
+    if (nslab > 1) RBQ_RANK_FETCH(1);
+    __syncthreads();
+    RBQ_RANK_FRAGS(0, 0, f0ah, f0al, f0bh, f0bl);
+    for (uint32_t s = 0; s < nslab; ++s) {
+        // the LDS reads of one K step run under the MFMAs of the other: step 1 of this slab is requested before
+        // the MFMAs of step 0, step 0 of the NEXT slab (complete in LDS once the barrier is passed) before those
+        // of step 1
+        const uint32_t cur = s & 1u;
+        RBQ_RANK_FRAGS(cur, 1, f1ah, f1al, f1bh, f1bl);
+        if (s + 1 < nslab) RBQ_RANK_STORE(cur ^ 1u);
+        if (s + 2 < nslab) RBQ_RANK_FETCH(s + 2);
+        RBQ_RANK_MMA(f0ah, f0al, f0bh, f0bl);
+        __builtin_amdgcn_sched_barrier(0); // keep these MFMAs in front of the barrier: they cover the reads of step 1
+        __syncthreads();
+        if (s + 1 < nslab) RBQ_RANK_FRAGS(cur ^ 1u, 0, f0ah, f0al, f0bh, f0bl);
+        RBQ_RANK_MMA(f1ah, f1al, f1bh, f1bl);
+    }
+#undef RBQ_RANK_FRAGS
+#undef RBQ_RANK_MMA
+#undef RBQ_RANK_FETCH
+#undef RBQ_RANK_STORE
+    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The query norms of
+    // all rows are fetched up front (one wait instead of one per row).
+    float qn[TM][16];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t qi = q0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            qn[a][r] = METRIC == 0 ? consts[qi < nq ? qi : nq - 1u].qnorm2 : 0.0f;
+        }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const uint32_t c = c0 + wn * 32 * TN + b * 32 + (lane & 31u);
+            const float cn = (METRIC == 0 && c < nlist) ? cnorm2[c] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t qi = q0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qi < nq && c < nlist) {
+                    const float dot = acc[a][b][r];
+                    scores[(size_t)qi * nlist + c] = METRIC == 0 ? fmaf(-2.0f, dot, qn[a][r] + cn) : dot;
+                }
+            }
+        }
+}
+
 // Canonical-order score of one (query, list) pair on 2 lanes: lane h owns the reference's accumulators
 // 4h..4h+3 (elements 8t+4h..8t+4h+3, one 16-byte load per step); the final sum adds the eight accumulators
 // in order 0..7 starting from -0.0 (Rust iter().sum()), then the scalar tail.  D % 4 == 0.

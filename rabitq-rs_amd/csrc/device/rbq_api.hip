@@ -695,16 +695,23 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             if (split_rank) {
                 // big problems: 128x128 tiles, 8 waves (each 64x32) — the tile traffic of the 4-wave form with twice
                 // the waves to hide the staging behind the MFMAs; small ones: 64x64 tiles, 4 waves
+#ifdef RBQ_RANK_SB
+#define RBQ_RANK_KERNEL k_rank_bf16
+#define RBQ_RANK_LDS(TM, TN, WM, WN) ((size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 144)
+#else
+#define RBQ_RANK_KERNEL k_rank_bf16_db
+#define RBQ_RANK_LDS(TM, TN, WM, WN) ((size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 80 * 2)
+#endif
 #define RBQ_LAUNCH_RANKB(M, TM, TN, WM, WN)                                                                            \
     do {                                                                                                               \
-        const size_t lds = (size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 144;                                        \
+        const size_t lds = RBQ_RANK_LDS(TM, TN, WM, WN);                                                               \
         static std::atomic<int> attr_dev_mask{0}; /* once per device: the call is slow and serialises launches */      \
         if (lds > 48 * 1024 && !(attr_dev_mask.load() & (1 << ix->device))) {                                          \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank_bf16<M, TM, TN, WM, WN>),                \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&RBQ_RANK_KERNEL<M, TM, TN, WM, WN>),            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
             attr_dev_mask.fetch_or(1 << ix->device);                                                                   \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_rank_bf16<M, TM, TN, WM, WN>), grid, dim3(64 * WM * WN), lds, stream,                    \
+        hipLaunchKernelGGL((RBQ_RANK_KERNEL<M, TM, TN, WM, WN>), grid, dim3(64 * WM * WN), lds, stream,                \
                            (const uint16_t*)w->rot_hi.p, (const uint16_t*)w->rot_lo.p, (const uint16_t*)ix->d_cent_hi, \
                            (const uint16_t*)ix->d_cent_lo, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2, \
                            (uint32_t)nq, nlist, D, (float*)w->scores.p);                                               \
