@@ -24,6 +24,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes a process's streams over 4 hardware queues by default; two of the batch streams on one
+# queue serialise their kernels.  Eight queues let every batch stream have its own (set before HIP starts).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
@@ -31,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=960)
     ap.add_argument("--nlist", type=int, default=4096)
@@ -47,7 +50,7 @@ def parse():
                     help="build the index with the GPU-side encoder only (large n: no CPU build, no oracle check)")
     ap.add_argument("--kmeans-iters", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], help="rbq_debug_set_option name=value (diagnostic A/B runs)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the batches are issued on, round-robin")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the batches are issued on, round-robin")
     return ap.parse_args()
 
 
@@ -254,7 +257,8 @@ def main():
     fence()
     # HIP events on the kernels' own stream, no host sync inside the timed region.  Only the roofline kernel is
     # timed here (two event records per launch); the other stages are timed in the single-stream pass below.
-    idx.profile_begin(stages=("scan",), every=int(os.environ.get("RBQ_BENCH_TAP_EVERY", "1")))
+    # (about 25 launches are sampled: an event pair on every launch costs a few per cent of the rate)
+    idx.profile_begin(stages=("scan",), every=int(os.environ.get("RBQ_BENCH_TAP_EVERY", str(max(1, a.steps // 25)))))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -269,7 +273,7 @@ def main():
     stage_ms = {s: idx.profile_stage(s) for s in ("prep", "rank", "select", "scan")}
     scan_ms, scan_launches = stage_ms["scan"]
     scan_bytes_total = idx.profile_scan_bytes()
-    per_launch_bytes = scan_bytes_total / max(scan_launches, 1)
+    per_launch_bytes = scan_bytes_total / max(a.steps, 1)  # the byte counter runs on every launch, the event taps on a sample
     achieved = per_launch_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
     ids = d_ids[0].cpu().numpy().view(np.uint64)

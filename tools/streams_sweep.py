@@ -22,10 +22,11 @@ for ns in [int(v) for v in os.environ.get("NS", "1,2,3,4,5,6,8").split(",")]:
     for i in range(3 * ns):
         step(i)
     torch.cuda.synchronize(dev)
-    n = 60
+    n = int(os.environ.get("N_STEPS", "60"))
     t0 = time.perf_counter()
     for i in range(n):
         step(i)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    print("streams %d (null stream %s): %.4f ms/step, %.0f q/s" % (ns, "used" if use_null else "not used", dt / n * 1e3, a.batch * n / dt), flush=True)
+    print("streams %d (null stream %s): %.4f ms/step, %.0f q/s (host enqueue %.4f ms/step)" % (ns, "used" if use_null else "not used", dt / n * 1e3, a.batch * n / dt, t_enq / n * 1e3), flush=True)
