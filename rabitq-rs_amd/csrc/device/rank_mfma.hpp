@@ -699,10 +699,16 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
             uint32_t rk[2] = {0, 0};
 #pragma unroll
             for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) my[u] = keys[tid + u * kThreads];
-            for (uint32_t j = 0; j < n; ++j) {
-                const uint64_t kj = keys[j];
-                rk[0] += kj < my[0] ? 1u : 0u;
-                rk[1] += kj < my[1] ? 1u : 0u;
+            // (wavefronts without a key skip the walk; the second key slot is only walked when n > 256)
+            const uint32_t wbase = tid & ~63u;
+            if (n > (uint32_t)kThreads) {
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint64_t kj = keys[j];
+                    rk[0] += kj < my[0] ? 1u : 0u;
+                    rk[1] += kj < my[1] ? 1u : 0u;
+                }
+            } else if (wbase < n) {
+                for (uint32_t j = 0; j < n; ++j) rk[0] += keys[j] < my[0] ? 1u : 0u;
             }
             __syncthreads();
 #pragma unroll
