@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
 
     for (uint32_t i = tid; i < D; i += kThreads) {
         rot_out[(size_t)q * D + i] = x[i];
-        if (rot_hi) { // split-bf16 image for k_rank_bf16
+        if (rot_hi) { // split-bf16 image for k_rank_bf16_db
             uint16_t h, l;
             bf16_split(x[i], h, l);
             rot_hi[(size_t)q * D + i] = h;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
         const float v = x[i];
         x2[i] = v * v;
         rot_out[(size_t)q * D + i] = v;
-        if (rot_hi) { // split-bf16 image for k_rank_bf16
+        if (rot_hi) { // split-bf16 image for k_rank_bf16_db
             uint16_t h, l;
             bf16_split(v, h, l);
             rot_hi[(size_t)q * D + i] = h;

@@ -3,10 +3,10 @@
 // Reference: search_fastscan's centroid ranking (src/ivf.rs:1782-1835) with math::l2_distance_sqr / dot in
 // their AVX2 lane order (src/math.rs:154-245).  Ranking all nq x nlist pairs in that exact order costs
 // 3*nq*nlist*D unfused VALU ops; instead
-//   k_rank_bf16    one split-bf16 MFMA GEMM gives APPROXIMATE scores
+//   k_rank_bf16_db one split-bf16 MFMA GEMM gives APPROXIMATE scores
 //                  A(q,c) = |q|^2 + |c|^2 - 2 q.c   (L2)   or   q.c   (IP)
 //                  with x = hi + lo + r (hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x|) and
-//                  q.c ~ qh.ch + qh.cl + ql.ch on v_mfma_f32_32x32x16_bf16 (products exact, f32 accumulate);
+//                  q.c ~ qh.ch + qh.cl + ql.ch on v_mfma_f32_32x32x8_bf16_1k (products exact, f32 accumulate);
 //                  the dropped terms are <= 3.01 * 2^-16 * sum|q_i||c_i| <= 1.51 * 2^-16 (|q|^2 + |c|^2)
 //   k_rank_mfma    the same scores from one f32 MFMA GEMM (v_mfma_f32_32x32x2_f32), used when D % 64 != 0
 //   k_select_mfma  per query: nprobe-th approximate score tau, shortlist {c : A(c) within 2*eps of tau},
@@ -111,160 +111,11 @@ __device__ __forceinline__ f32x16 mfma_x8(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b1, c, 0, 0, 0);
 }
 
-// Split-bf16 GEMM: 64*TW x 64*TW tile per 256-thread workgroup, K slabs of 64 staged through LDS (rows padded to
-// 144 bytes: the 16 lanes of a ds_read_b128 group then hit 16 distinct 4-bank sets), next slab prefetched into
-// registers while the current one feeds the MFMAs.  D % 64 == 0.
-// dynamic LDS: Ah | Al [BM][144 B] | Bh | Bl [BN][144 B]
-template <int METRIC, int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16(const uint16_t* __restrict__ rot_hi, const uint16_t* __restrict__ rot_lo,
-                                                   const uint16_t* __restrict__ cent_hi, const uint16_t* __restrict__ cent_lo,
-                                                   const QueryConsts* __restrict__ consts,
-                                                   const float* __restrict__ cnorm2, uint32_t nq, uint32_t nlist,
-                                                   uint32_t D, float* __restrict__ scores) {
-    constexpr int NT = 64 * WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, BK = 64, LDB = BK * 2 + 16, SEG = BK / 8;
-    constexpr int NLA = BM * SEG / NT, NLB = BN * SEG / NT; // 16-byte loads per thread and array
-    static_assert(BM * SEG % NT == 0 && BN * SEG % NT == 0, "tile rows must divide over the threads");
-    extern __shared__ __align__(16) unsigned char smraw[];
-    unsigned char* sAh = smraw;
-    unsigned char* sAl = sAh + BM * LDB;
-    unsigned char* sBh = sAl + BM * LDB;
-    unsigned char* sBl = sBh + BN * LDB;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, wm = w / WN, wn = w % WN;
-    const uint32_t q0 = blockIdx.y * BM, c0 = blockIdx.x * BN;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    // per-thread source rows (clamped: rows past the end compute scores that are never stored) and LDS slots
-    const unsigned char* ga_h[NLA];
-    const unsigned char* ga_l[NLA];
-    const unsigned char* gb_h[NLB];
-    const unsigned char* gb_l[NLB];
-    uint32_t soa[NLA], sob[NLB];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const uint32_t idx = tid + (uint32_t)NT * i, row = idx / SEG, seg = idx % SEG;
-        const uint32_t ra = q0 + row < nq ? q0 + row : nq - 1u;
-        ga_h[i] = reinterpret_cast<const unsigned char*>(rot_hi) + (size_t)ra * D * 2 + seg * 16;
-        ga_l[i] = reinterpret_cast<const unsigned char*>(rot_lo) + (size_t)ra * D * 2 + seg * 16;
-        soa[i] = row * LDB + seg * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const uint32_t idx = tid + (uint32_t)NT * i, row = idx / SEG, seg = idx % SEG;
-        const uint32_t rb = c0 + row < nlist ? c0 + row : nlist - 1u;
-        gb_h[i] = reinterpret_cast<const unsigned char*>(cent_hi) + (size_t)rb * D * 2 + seg * 16;
-        gb_l[i] = reinterpret_cast<const unsigned char*>(cent_lo) + (size_t)rb * D * 2 + seg * 16;
-        sob[i] = row * LDB + seg * 16;
-    }
-    u32x4 pah[NLA], pal[NLA], pbh[NLB], pbl[NLB]; // native vectors: the HIP uint4 struct kept these arrays in scratch
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i]);
-        pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i]);
-        pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i]);
-    }
-    for (uint32_t k0 = 0; k0 < D; k0 += BK) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            *reinterpret_cast<u32x4*>(sAh + soa[i]) = pah[i];
-            *reinterpret_cast<u32x4*>(sAl + soa[i]) = pal[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            *reinterpret_cast<u32x4*>(sBh + sob[i]) = pbh[i];
-            *reinterpret_cast<u32x4*>(sBl + sob[i]) = pbl[i];
-        }
-        __syncthreads();
-        {
-            const uint32_t kn = k0 + BK < D ? k0 + BK : k0; // last slab: reload (unused)
-#pragma unroll
-            for (int i = 0; i < NLA; ++i) {
-                pah[i] = *reinterpret_cast<const u32x4*>(ga_h[i] + (size_t)kn * 2);
-                pal[i] = *reinterpret_cast<const u32x4*>(ga_l[i] + (size_t)kn * 2);
-            }
-#pragma unroll
-            for (int i = 0; i < NLB; ++i) {
-                pbh[i] = *reinterpret_cast<const u32x4*>(gb_h[i] + (size_t)kn * 2);
-                pbl[i] = *reinterpret_cast<const u32x4*>(gb_l[i] + (size_t)kn * 2);
-            }
-        }
-#pragma unroll
-        for (int kc = 0; kc < BK / 16; ++kc) {
-            // A/B operand of 32x32x16: lane l holds row (l & 31), k = 8 * (l >> 5) .. + 7
-            const uint32_t fo = (lane & 31u) * LDB + kc * 32 + (lane >> 5) * 16;
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const uint32_t ra = (wm * 32 * TM + a * 32) * LDB + fo;
-                ah[a] = *reinterpret_cast<const bf16x8*>(sAh + ra);
-                al[a] = *reinterpret_cast<const bf16x8*>(sAl + ra);
-            }
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const uint32_t rb = (wn * 32 * TN + b * 32) * LDB + fo;
-                bh[b] = *reinterpret_cast<const bf16x8*>(sBh + rb);
-                bl[b] = *reinterpret_cast<const bf16x8*>(sBl + rb);
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used.  With it in this GEMM, the
-                    // workgroup-per-query k_prep of a NEIGHBOURING stream computed wrong LUT bytes (one 16-lane pass
-                    // of a quantisation result at a time, tests/diag/stress3.py) although neither kernel writes outside
-                    // its own buffers; the K=8 form below never showed it, nor does k_prep_wave with either form,
-                    // and a stand-alone MFMA-beside-division test (tools/repro/) stays clean.  Root cause not
-                    // established; the combination that ships is the one every stress run has been clean with
-                    // (tests/test_gpu_parity.py::test_concurrent_streams_match_oracle guards it).
-#ifdef RBQ_MFMA_X16
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-#else
-                    // two K=8 steps per 8-element fragment: both operands use the same k subset per lane half
-                    acc[a][b] = mfma_x8(al[a], bh[b], acc[a][b]);
-                    acc[a][b] = mfma_x8(ah[a], bl[b], acc[a][b]);
-                    acc[a][b] = mfma_x8(ah[a], bh[b], acc[a][b]);
-#endif
-                }
-        }
-        __syncthreads();
-    }
-    // C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const uint32_t c = c0 + wn * 32 * TN + b * 32 + (lane & 31u);
-            const float cn = (METRIC == 0 && c < nlist) ? cnorm2[c] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t qi = q0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (qi < nq && c < nlist) {
-                    const float dot = acc[a][b][r];
-                    float v = dot;
-                    if (METRIC == 0) {
-                        const float qn = consts[qi].qnorm2;
-                        v = fmaf(-2.0f, dot, qn + cn);
-                    }
-                    scores[(size_t)qi * nlist + c] = v;
-                }
-            }
-        }
-}
-
-// The same GEMM with K slabs of 32 double-buffered in LDS: slab s+1 is written (from the registers the previous
-// iteration filled) and slab s+2 requested BEFORE the MFMAs of slab s, and one barrier per slab closes the
-// iteration — the staging of the next slab runs under the matrix work of this one instead of between two barriers.
+// Split-bf16 GEMM (32*TM*WM x 32*TN*WN tile per workgroup of WM*WN wavefronts, each wavefront a 32*TM x 32*TN
+// sub-tile of 32x32 MFMA blocks) with K slabs of 32 double-buffered in LDS: slab s+1 is written (from the registers
+// the previous iteration filled) and slab s+2 requested BEFORE the MFMAs of slab s, and one barrier per slab closes
+// the iteration — the staging of the next slab runs under the matrix work of this one instead of between two
+// barriers.
 // Rows are padded to 80 bytes (16 lanes of a ds_read_b128 group: 16 distinct 4-bank sets).  D % 32 == 0.
 // dynamic LDS: 2 x { Ah | Al [BM][80 B] | Bh | Bl [BN][80 B] }
 template <int METRIC, int TM, int TN, int WM, int WN>
@@ -353,7 +204,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16_db(const uint16_t* _
             BL[b] = *reinterpret_cast<const bf16x8*>(sBh + BN * LDB + rb);                                             \
         }                                                                                                              \
     } while (0)
-    // K=8 MFMA form on purpose: see k_rank_bf16
+    // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used.  With it in this GEMM, the
+    // workgroup-per-query k_prep of a NEIGHBOURING stream computed wrong LUT bytes (one 16-lane pass
+    // of a quantisation result at a time, tests/diag/stress3.py) although neither kernel writes outside
+    // its own buffers; the K=8 form below never showed it, nor does k_prep_wave with either form,
+    // and a stand-alone MFMA-beside-division test (tools/repro/) stays clean.  Root cause not
+    // established; the combination that ships is the one every stress run has been clean with
+    // (tests/test_gpu_parity.py::test_concurrent_streams_match_oracle guards it).
 #define RBQ_RANK_MMA(AH, AL, BH, BL)                                                                                   \
     _Pragma("unroll") for (int a = 0; a < TM; ++a) _Pragma("unroll") for (int b = 0; b < TN; ++b) {                    \
         acc[a][b] = mfma_x8(AL[a], BH[b], acc[a][b]);                                                                  \

@@ -252,7 +252,7 @@ int finish_centroid_arrays(rbq_index* ix, const std::vector<float>& cent) {
     ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
     int rc;
     if ((rc = upload(&ix->d_cnorm2, cn))) return rc;
-    std::vector<uint16_t> ch(cent.size()), cl(cent.size()); // split-bf16 image of the centroids (k_rank_bf16)
+    std::vector<uint16_t> ch(cent.size()), cl(cent.size()); // split-bf16 image of the centroids (k_rank_bf16_db)
     for (size_t i = 0; i < cent.size(); ++i) bf16_split(cent[i], ch[i], cl[i]);
     if ((rc = upload(&ix->d_cent_hi, ch))) return rc;
     if ((rc = upload(&ix->d_cent_lo, cl))) return rc;
@@ -640,7 +640,7 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
     if ((rc = w->wl.ensure(nq * wl_stride * sizeof(StreamItem)))) return rc;
     if ((rc = w->nstream.ensure(nq * 4))) return rc;
     if ((rc = w->nvec.ensure(nq * 8))) return rc;
-    const bool split_rank = !ix->exact_rank && !ix->f32_rank && D % 64 == 0; // k_rank_bf16 (else k_rank_mfma)
+    const bool split_rank = !ix->exact_rank && !ix->f32_rank && D % 64 == 0; // k_rank_bf16_db (else k_rank_mfma)
     if (split_rank) {
         if ((rc = w->rot_hi.ensure(nq * D * 2))) return rc;
         if ((rc = w->rot_lo.ensure(nq * D * 2))) return rc;
@@ -695,13 +695,8 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
             if (split_rank) {
                 // big problems: 128x128 tiles, 8 waves (each 64x32) — the tile traffic of the 4-wave form with twice
                 // the waves to hide the staging behind the MFMAs; small ones: 64x64 tiles, 4 waves
-#ifdef RBQ_RANK_SB
-#define RBQ_RANK_KERNEL k_rank_bf16
-#define RBQ_RANK_LDS(TM, TN, WM, WN) ((size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 144)
-#else
 #define RBQ_RANK_KERNEL k_rank_bf16_db
-#define RBQ_RANK_LDS(TM, TN, WM, WN) ((size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 80 * 2)
-#endif
+#define RBQ_RANK_LDS(TM, TN, WM, WN) ((size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 80 * 2) /* two slabs of 32, rows of 80 B */
 #define RBQ_LAUNCH_RANKB(M, TM, TN, WM, WN)                                                                            \
     do {                                                                                                               \
         const size_t lds = RBQ_RANK_LDS(TM, TN, WM, WN);                                                               \
