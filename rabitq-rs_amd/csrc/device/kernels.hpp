@@ -490,7 +490,9 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
             case 256: rotate_fhtkac_wave<4>(x, qin, dim, D, flips, fac, lane); break;
             case 512: rotate_fhtkac_wave<8>(x, qin, dim, D, flips, fac, lane); break;
             case 1024: rotate_fhtkac_wave<16>(x, qin, dim, D, flips, fac, lane); break;
-            default: rotate_fhtkac_wave<32>(x, qin, dim, D, flips, fac, lane); break;
+            case 2048: rotate_fhtkac_wave<32>(x, qin, dim, D, flips, fac, lane); break;
+            // dim < 64 (transform shorter than a wavefront) or >= 4096: the generic LDS butterflies
+            default: rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, flips, trunc, fac, lane); break;
         }
     } else {
         rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, rot_blob, trunc, fac, lane);

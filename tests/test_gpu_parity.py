@@ -45,6 +45,11 @@ CASES = [
     pytest.param(3000, 48, 24, 3, 0, 0, 32, 10, 6, False, id="matrix_rotator_d48_codepad_3bit_L2"),
     pytest.param(5000, 320, 40, 7, 0, 1, 16, 100, 20, False, id="d320_top100"),
     pytest.param(2000, 64, 16, 7, 0, 1, 16, 1, 4, False, id="top1"),
+    # FHT-Kac transforms shorter than a wavefront (dim < 64: trunc = 16 / 32, padded to 64) take the generic LDS
+    # butterflies in k_prep_wave; tests/diag/soak.py found them going through the 2048-point branch (seeds 1004, 1009)
+    pytest.param(600, 16, 13, 1, 0, 1, 30, 5, 6, False, id="kac_d16_trunc16_1bit_L2"),
+    pytest.param(1500, 24, 12, 7, 1, 1, 20, 10, 5, False, id="kac_d24_trunc16_7bit_IP"),
+    pytest.param(1500, 40, 12, 3, 0, 1, 20, 10, 12, False, id="kac_d40_trunc32_3bit_L2"),
 ]
 
 
@@ -419,7 +424,7 @@ def _random_case(seed):
     return n, dim, nlist, bits, metric, rot, nq, top_k, nprobe
 
 
-@pytest.mark.parametrize("seed", list(range(100, 124)))
+@pytest.mark.parametrize("seed", list(range(100, 124)) + [1004, 1009])
 def test_random_configurations_match_oracle(seed):
     """Seeded random shapes (dimension padding, tiny lists, nprobe > nlist, top_k beyond the candidate count,
     top_k >= 64 = LDS heap, both metrics, both rotators): ids, counts, scores and diagnostics equal the oracle's."""
