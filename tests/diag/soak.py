@@ -13,19 +13,79 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+import numpy as np
+
+
+def wide_case(seed):
+    """A wider draw than the test's generator: padded dimensions up to 2048, odd dimensions, up to 300 lists and
+    30 000 vectors, top_k around the 63/64 heap switch, random id filters (also shorter than the id range), and the
+    device encoder in place of the CPU builder's arrays."""
+    rng = np.random.default_rng(seed)
+    rot = int(rng.integers(0, 4) != 0)
+    dim = int(rng.choice([16, 24, 33, 40, 63, 64, 65, 100, 128, 130, 200, 256, 300, 384, 512, 700, 768, 960, 1024, 1100,
+                          1536, 2000, 2048])) if rot == 1 else int(rng.choice([16, 32, 48, 64, 96, 128, 192, 256]))
+    bits = int(rng.choice([1, 3, 7]))
+    metric = int(rng.integers(0, 2))
+    nlist = int(rng.integers(2, 300))
+    nmax = max(nlist + 1, min(30000, 6_000_000 // dim))
+    n = int(rng.integers(nlist, nmax))
+    nq = int(rng.integers(1, 64))
+    top_k = int(rng.choice([1, 2, 5, 10, 17, 63, 64, 65, 100, 300]))
+    nprobe = int(rng.integers(1, nlist + 3))
+    filt = float(rng.choice([0.0, 0.0, 0.0, 0.01, 0.1, 0.5, 0.9]))
+    short = bool(rng.integers(0, 2))
+    enc = bool(rng.integers(0, 3) == 0)
+    return dict(n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, rot=rot, nq=nq, top_k=top_k, nprobe=nprobe,
+                filt=filt, short=short, enc=enc)
+
+
+def run_wide(seed):
+    import rabitq_rs_amd as rq
+    c = wide_case(seed)
+    data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
+                                       rotator=c["rot"], seed=seed, normalize=(c["metric"] == 1))
+    if c["enc"]:
+        import torch
+        # build_index clusters internally; redo the clustering here so that the assignment is known
+        cent, assign = rq.builder.kmeans(data, c["nlist"], 5, seed + 7)
+        built = rq.builder.train_with_clusters(data, cent, assign, c["bits"], c["metric"], c["rot"], seed + 8, True)
+        xd = torch.from_numpy(data).cuda()
+        ad = torch.from_numpy(assign.astype(np.int32)).cuda()
+        idx = rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ad.data_ptr(), c["n"], built.t_const)
+    else:
+        idx = rq.IvfRabitqIndex.from_built(built)
+    q = conftest.make_dataset(c["nq"], c["dim"], max(c["nlist"] // 4, 1), seed + 1000, normalize=(c["metric"] == 1))
+    words, nbits = None, 0
+    if c["filt"] > 0.0:
+        rng = np.random.default_rng(seed + 5)
+        allowed = rng.choice(c["n"], max(1, int(c["filt"] * c["n"])), replace=False)
+        nbits = int(allowed.max()) + 1
+        if c["short"]:
+            nbits = max(1, nbits // 2)
+            allowed = allowed[allowed < nbits]
+        words = np.zeros((nbits + 31) // 32, np.uint32)
+        if allowed.size:
+            np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+    t._compare(built, idx, q, c["top_k"], c["nprobe"], words, nbits)
+    idx.close()
+
 bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        t.test_random_configurations_match_oracle(seed)
+        if wide:
+            run_wide(seed)
+        else:
+            t.test_random_configurations_match_oracle(seed)
         harness = []
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, wide_case(seed) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, wide_case(seed) if wide else t._random_case(seed), msg, flush=True)
         harness.append(msg)
         if len(harness) >= 3 and len(set(harness[-3:])) == 1:
             print("aborting: harness error, no parity information in this run")
