@@ -11,6 +11,21 @@ _LIB = None
 LIB_PATH = os.environ.get("RBQ_LIB_PATH") or os.path.join(_HERE, "csrc", "librbq.so")  # override: kernel A/B builds
 
 
+def _hip_runtime_of_torch_first():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so and asks for it by the
+    unversioned name; librbq.so asks for libamdhip64.so.7.  If torch is loaded first, librbq.so binds to torch's copy
+    (same SONAME) and the process has one runtime.  The other way round the loader maps a SECOND runtime for torch,
+    which then sees no GPU ("No HIP GPUs are available": found by tests/diag/soak.py, whose first seed used this
+    library before torch).  So when torch is installed it is imported before librbq.so is mapped; without torch
+    (a C / Rust host, or a torch-less Python) there is only the system runtime and nothing to order."""
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
 def lib():
     """Load csrc/librbq.so (HIP, gfx950). Fails loudly — there is no CPU fallback."""
     global _LIB
@@ -19,6 +34,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} missing: the HIP extension must be built first "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        _hip_runtime_of_torch_first()
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.rbq_index_create.restype = C.c_int

@@ -5,6 +5,7 @@ A harness error (the same non-assertion exception three times in a row) aborts t
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401  (first, as under pytest: one HIP runtime per process, see rabitq_rs_amd/index.py)
 import conftest  # noqa: F401  (inserts ROOT and ROOT/oracle into sys.path in the order the tests use)
 import __graft_entry__ as g
 g.build_cpu_libs()
@@ -36,8 +37,12 @@ def wide_case(seed):
     filt = float(rng.choice([0.0, 0.0, 0.0, 0.01, 0.1, 0.5, 0.9]))
     short = bool(rng.integers(0, 2))
     enc = bool(rng.integers(0, 3) == 0)
-    return dict(n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, rot=rot, nq=nq, top_k=top_k, nprobe=nprobe,
+    rbq1 = (not enc) and bool(rng.integers(0, 3) == 0)  # through save_rbq1 -> rbq_index_load_rbq1
+    return dict(rbq1=rbq1, n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, rot=rot, nq=nq, top_k=top_k, nprobe=nprobe,
                 filt=filt, short=short, enc=enc)
+
+
+stats = dict(queries=0, results=0, encoder=0, rbq1=0, filtered=0)
 
 
 def run_wide(seed):
@@ -53,6 +58,8 @@ def run_wide(seed):
         xd = torch.from_numpy(data).cuda()
         ad = torch.from_numpy(assign.astype(np.int32)).cuda()
         idx = rq.IvfRabitqIndex.build_on_device(built.hdr_ptr, cent, xd.data_ptr(), ad.data_ptr(), c["n"], built.t_const)
+    elif c["rbq1"]:
+        idx = rq.IvfRabitqIndex.load_from_bytes(built.save_rbq1())
     else:
         idx = rq.IvfRabitqIndex.from_built(built)
     q = conftest.make_dataset(c["nq"], c["dim"], max(c["nlist"] // 4, 1), seed + 1000, normalize=(c["metric"] == 1))
@@ -67,8 +74,13 @@ def run_wide(seed):
         words = np.zeros((nbits + 31) // 32, np.uint32)
         if allowed.size:
             np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
-    t._compare(built, idx, q, c["top_k"], c["nprobe"], words, nbits)
+    ids, sc, cnt = t._compare(built, idx, q, c["top_k"], c["nprobe"], words, nbits)
     idx.close()
+    stats["queries"] += len(q)
+    stats["results"] += int(cnt.sum())
+    stats["encoder"] += int(c["enc"])
+    stats["rbq1"] += int(c["rbq1"])
+    stats["filtered"] += int(c["filt"] > 0.0)
 
 bad, harness = [], []
 t0 = time.time()
@@ -86,6 +98,8 @@ for seed in range(first, last):
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
         print("ERROR seed", seed, wide_case(seed) if wide else t._random_case(seed), msg, flush=True)
+        if os.environ.get("SOAK_TB"):
+            traceback.print_exc()
         harness.append(msg)
         if len(harness) >= 3 and len(set(harness[-3:])) == 1:
             print("aborting: harness error, no parity information in this run")
@@ -93,4 +107,6 @@ for seed in range(first, last):
     if (seed - first) % 50 == 49:
         print("... %d seeds, %d mismatches, %.0f s" % (seed - first + 1, len(bad), time.time() - t0), flush=True)
 print("done: %d seeds, mismatches: %s" % (last - first, bad))
+if wide:
+    print("compared:", stats)
 sys.exit(1 if bad else 0)

@@ -534,3 +534,28 @@ def test_bench_two_rank_rehearsal():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["streams_identical"] and d["value"] > 0 and d["roofline"]["launches"] == 4
+
+
+def test_library_first_then_torch_in_a_fresh_process():
+    """A fresh Python process that searches through librbq.so BEFORE it ever imports torch must still find the GPU
+    from torch afterwards (one HIP runtime per process: rabitq_rs_amd.index._hip_runtime_of_torch_first).  This
+    pytest process cannot show it — collection imports torch first — so it runs in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import conftest, numpy as np, rabitq_rs_amd as rq\n"
+        "data, built = conftest.build_index(n=600, dim=64, nlist=6, total_bits=7)\n"
+        "idx = rq.IvfRabitqIndex.from_built(built)\n"
+        "ids, sc, cnt = idx.batch_search_raw(data[:4], rq.SearchParams(5, 3))[:3]\n"
+        "assert (cnt == 5).all()\n"
+        "import torch\n"
+        "x = torch.from_numpy(data).cuda()\n"
+        "print('ok', torch.cuda.device_count(), float(x.sum().item()) == float(x.cpu().sum().item()))\n"
+    ) % (root, os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("ok 1")
