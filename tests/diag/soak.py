@@ -14,7 +14,8 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
-wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams")
+streams_mode = len(sys.argv) > 3 and sys.argv[3] == "streams"
 import numpy as np
 
 
@@ -43,6 +44,58 @@ def wide_case(seed):
 
 
 stats = dict(queries=0, results=0, encoder=0, rbq1=0, filtered=0)
+
+
+def streams_case(seed):
+    """Larger indexes searched on four caller streams at once (bench.py's pipelining), several rounds: kernels of
+    different batches share CUs, which is where cross-kernel interference would show."""
+    rng = np.random.default_rng(seed)
+    dim = int(rng.choice([128, 384, 768, 960, 960, 1536]))
+    bits = int(rng.choice([1, 3, 7, 7]))
+    metric = int(rng.integers(0, 2))
+    nlist = int(rng.choice([64, 128, 256, 512]))
+    n = int(rng.integers(20000, max(20001, min(150000, 60_000_000 // dim))))
+    nq = int(rng.choice([128, 256, 512, 1024]))
+    top_k = int(rng.choice([1, 10, 10, 100]))
+    nprobe = int(rng.choice([8, 16, 32, 64]))
+    return dict(n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, nq=nq, top_k=top_k, nprobe=nprobe)
+
+
+def run_streams(seed):
+    import rabitq_rs_amd as rq
+    c = streams_case(seed)
+    dev = torch.device("cuda", 0)
+    data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
+                                       rotator=1, seed=seed, normalize=(c["metric"] == 1))
+    idx = rq.IvfRabitqIndex.from_built(built)
+    nq, top_k, nprobe, ns = c["nq"], c["top_k"], c["nprobe"], 4
+    q = conftest.make_dataset(nq, c["dim"], max(c["nlist"] // 4, 1), seed + 1000, normalize=(c["metric"] == 1))
+    rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, top_k, nprobe)
+    assert rc == 0
+    qd = torch.from_numpy(q).to(dev)
+    ss = [torch.cuda.Stream(dev) for _ in range(ns)]
+    d_ids = [torch.zeros(nq, top_k, dtype=torch.int64, device=dev) for _ in range(ns)]
+    d_sc = [torch.zeros(nq, top_k, dtype=torch.float32, device=dev) for _ in range(ns)]
+    d_cnt = [torch.zeros(nq, dtype=torch.int32, device=dev) for _ in range(ns)]
+    torch.cuda.synchronize(dev)
+    for rep in range(6):
+        for i in range(ns):
+            idx.search_batch_device(qd.data_ptr(), nq, c["dim"], top_k, nprobe, d_ids[i].data_ptr(), d_sc[i].data_ptr(),
+                                    d_cnt[i].data_ptr(), stream=ss[i].cuda_stream)
+        torch.cuda.synchronize(dev)
+        for i in range(ns):
+            got = d_ids[i].cpu().numpy().view(np.uint64)
+            cnt = d_cnt[i].cpu().numpy().view(np.uint32)
+            assert np.array_equal(cnt, ocnt), f"rep {rep} stream {i}: counts differ"
+            bad = np.nonzero((got != oids).any(axis=1))[0]
+            assert bad.size == 0, f"rep {rep} stream {i}: ids differ for queries {bad[:10]}"
+            sc = d_sc[i].cpu().numpy()
+            for qi in range(nq):
+                k = int(cnt[qi])
+                np.testing.assert_allclose(sc[qi, :k], osc[qi, :k], rtol=t.RTOL, atol=0)
+            stats["queries"] += nq
+            stats["results"] += int(cnt.sum())
+    idx.close()
 
 
 def run_wide(seed):
@@ -86,7 +139,9 @@ bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        if wide:
+        if streams_mode:
+            run_streams(seed)
+        elif wide:
             run_wide(seed)
         else:
             t.test_random_configurations_match_oracle(seed)
@@ -94,10 +149,10 @@ for seed in range(first, last):
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, wide_case(seed) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, (streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, wide_case(seed) if wide else t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, (streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
         if os.environ.get("SOAK_TB"):
             traceback.print_exc()
         harness.append(msg)
