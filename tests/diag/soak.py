@@ -14,7 +14,8 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
-wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams")
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg")
+mstg_mode = len(sys.argv) > 3 and sys.argv[3] == "mstg"
 streams_mode = len(sys.argv) > 3 and sys.argv[3] == "streams"
 import numpy as np
 
@@ -59,6 +60,21 @@ def streams_case(seed):
     top_k = int(rng.choice([1, 10, 10, 100]))
     nprobe = int(rng.choice([8, 16, 32, 64]))
     return dict(n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, nq=nq, top_k=top_k, nprobe=nprobe)
+
+
+def mstg_case(seed):
+    rng = np.random.default_rng(seed)
+    return dict(metric=int(rng.integers(0, 2)), bits=int(rng.choice([1, 3, 7])),
+                dim=int(rng.choice([64, 128, 192, 256, 384, 768])), nlist=int(rng.integers(3, 120)),
+                n=int(rng.integers(300, 20000)), nq=int(rng.integers(2, 60)), top_k=int(rng.choice([1, 5, 10, 64, 100, 300])))
+
+
+def run_mstg(seed):
+    c = mstg_case(seed)
+    built, q, lists, counts = t._mstg_case(c["metric"], c["bits"], dim=c["dim"], n=max(c["n"], c["nlist"] * 2), nlist=c["nlist"],
+                                           nq=c["nq"], seed=seed)
+    t._mstg_compare(built, q, lists, counts, c["metric"], top_ks=(c["top_k"],))
+    stats["queries"] += len(q)
 
 
 def run_streams(seed):
@@ -139,7 +155,9 @@ bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        if streams_mode:
+        if mstg_mode:
+            run_mstg(seed)
+        elif streams_mode:
             run_streams(seed)
         elif wide:
             run_wide(seed)
@@ -149,10 +167,10 @@ for seed in range(first, last):
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, (streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, (mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, (streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, (mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
         if os.environ.get("SOAK_TB"):
             traceback.print_exc()
         harness.append(msg)

@@ -264,27 +264,54 @@ def _mstg_case(metric, bits, dim=128, n=6000, nlist=48, nq=40, seed=31):
 @pytest.mark.parametrize("metric,bits", [(0, 7), (1, 7), (0, 1), (0, 3)])
 def test_mstg_posting_scan_matches_oracle(metric, bits):
     built, q, lists, counts = _mstg_case(metric, bits)
+    _mstg_compare(built, q, lists, counts, metric)
+
+
+def _mstg_compare(built, q, lists, counts, metric, top_ks=(10, 100)):
     idx = rq.IvfRabitqIndex.from_built(built)
-    for top_k in (10, 100):
+    for top_k in top_ks:
         rc, oids, osc, ocnt = oracle.posting_scan_batch(built, q, top_k, lists, counts)
         assert rc == 0
         ids, sc, cnt = idx.posting_scan(q, top_k, lists, counts)
         assert np.array_equal(cnt, ocnt) and cnt[0] == 0
+        # the oracle's list a little past the cut: a candidate TIED with the last returned one may be inside for one
+        # side and outside for the other — the reference partitions with select_nth_unstable_by on the distance alone
+        # (src/mstg/index.rs:185-203), so which of them is returned is not defined there either
+        ext = 64
+        rc2, xids, xsc, xcnt = oracle.posting_scan_batch(built, q, top_k + ext, lists, counts)
+        assert rc2 == 0
         for i in range(len(q)):
             c = int(cnt[i])
             if c == 0:
                 continue
+            assert np.array_equal(xsc[i, :c].view(np.uint32), osc[i, :c].view(np.uint32))  # the longer list extends the shorter
             assert np.array_equal(sc[i, :c].view(np.uint32) & 0x7fffffff if metric == 0 else sc[i, :c].view(np.uint32),
                                   osc[i, :c].view(np.uint32) & 0x7fffffff if metric == 0 else osc[i, :c].view(np.uint32))
             assert (np.diff(sc[i, :c]) >= 0).all()
             if metric == 0:
                 assert (sc[i, :c] >= 0).all()  # L2 estimates clamped at 0
-            # ids agree wherever the distance is unique (the reference leaves ties unordered)
+            # ids agree wherever the distance is unique (the reference leaves ties unordered) — unique also with
+            # respect to the first candidate past the cut
             uniq = np.ones(c, bool)
             uniq[1:] &= sc[i, 1:c] != sc[i, :c - 1]
             uniq[:-1] &= sc[i, :c - 1] != sc[i, 1:c]
+            xc = int(xcnt[i])
+            cut_tie = xc > c and xsc[i, c] == osc[i, c - 1]
+            if cut_tie:
+                assert xc < top_k + ext or xsc[i, xc - 1] != osc[i, c - 1], "tie group longer than the look-ahead"
+                uniq &= sc[i, :c] != osc[i, c - 1]
             assert np.array_equal(ids[i, :c][uniq], oids[i, :c][uniq])
-            assert sorted(ids[i, :c].tolist()) == sorted(oids[i, :c].tolist())
+            if not cut_tie:
+                assert sorted(ids[i, :c].tolist()) == sorted(oids[i, :c].tolist())
+            else:
+                # below the tied distance the id sets are equal; at it, the device's ids are candidates that the
+                # oracle's longer list holds at exactly that distance, and as many of them as the oracle returned
+                d = osc[i, c - 1]
+                lo_g, lo_o = sc[i, :c] != d, osc[i, :c] != d
+                assert sorted(ids[i, :c][lo_g].tolist()) == sorted(oids[i, :c][lo_o].tolist())
+                pool = set(xids[i, :xc][xsc[i, :xc] == d].tolist())
+                tied = ids[i, :c][~lo_g].tolist()
+                assert len(tied) == int((~lo_o).sum()) and len(set(tied)) == len(tied) and set(tied) <= pool
     idx.close()
 
 
