@@ -14,7 +14,8 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
-wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg")
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties")
+ties_mode = len(sys.argv) > 3 and sys.argv[3] == "ties"
 mstg_mode = len(sys.argv) > 3 and sys.argv[3] == "mstg"
 streams_mode = len(sys.argv) > 3 and sys.argv[3] == "streams"
 import numpy as np
@@ -60,6 +61,37 @@ def streams_case(seed):
     top_k = int(rng.choice([1, 10, 10, 100]))
     nprobe = int(rng.choice([8, 16, 32, 64]))
     return dict(n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, nq=nq, top_k=top_k, nprobe=nprobe)
+
+
+def ties_case(seed):
+    """Indexes made of a few distinct vectors repeated many times: every distance occurs in runs of equal values, so the
+    top-k goes through the exact-heap re-run (the reference's BinaryHeap order decides which of the tied ids stay)."""
+    rng = np.random.default_rng(seed)
+    dim = int(rng.choice([32, 64, 128, 200, 384, 960]))
+    nlist = int(rng.integers(2, 40))
+    n = int(rng.integers(max(200, nlist * 4), 6000))
+    return dict(dim=dim, nlist=nlist, n=n, distinct=int(rng.integers(3, max(4, n // 8))), bits=int(rng.choice([1, 3, 7])),
+                metric=int(rng.integers(0, 2)), nq=int(rng.integers(1, 40)), top_k=int(rng.choice([1, 2, 5, 10, 17, 63, 64, 100])),
+                nprobe=int(rng.integers(1, nlist + 1)), from_data=bool(rng.integers(0, 2)))
+
+
+def run_ties(seed):
+    import rabitq_rs_amd as rq
+    c = ties_case(seed)
+    rng = np.random.default_rng(seed + 3)
+    base = conftest.make_dataset(c["distinct"], c["dim"], max(c["nlist"] // 2, 1), seed, normalize=(c["metric"] == 1))
+    data = base[rng.integers(0, c["distinct"], c["n"])].copy()
+    data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
+                                       rotator=1, seed=seed, normalize=False, data=data)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    # queries: members of the index (distance ties at zero as well) or fresh draws
+    q = data[rng.integers(0, c["n"], c["nq"])].copy() if c["from_data"] else \
+        conftest.make_dataset(c["nq"], c["dim"], max(c["nlist"] // 2, 1), seed + 1000, normalize=(c["metric"] == 1))
+    ids, sc, cnt = t._compare(built, idx, q, c["top_k"], c["nprobe"])
+    stats["queries"] += len(q)
+    stats["results"] += int(cnt.sum())
+    stats["restarts"] = stats.get("restarts", 0) + int(idx.heap_restarts())
+    idx.close()
 
 
 def mstg_case(seed):
@@ -155,7 +187,9 @@ bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        if mstg_mode:
+        if ties_mode:
+            run_ties(seed)
+        elif mstg_mode:
             run_mstg(seed)
         elif streams_mode:
             run_streams(seed)
@@ -167,10 +201,10 @@ for seed in range(first, last):
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, (mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, (ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, (mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, (ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
         if os.environ.get("SOAK_TB"):
             traceback.print_exc()
         harness.append(msg)
