@@ -14,7 +14,8 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
-wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties")
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties", "lists")
+lists_mode = len(sys.argv) > 3 and sys.argv[3] == "lists"
 ties_mode = len(sys.argv) > 3 and sys.argv[3] == "ties"
 mstg_mode = len(sys.argv) > 3 and sys.argv[3] == "mstg"
 streams_mode = len(sys.argv) > 3 and sys.argv[3] == "streams"
@@ -91,6 +92,33 @@ def run_ties(seed):
     stats["queries"] += len(q)
     stats["results"] += int(cnt.sum())
     stats["restarts"] = stats.get("restarts", 0) + int(idx.heap_restarts())
+    idx.close()
+
+
+def lists_case(seed):
+    """Many lists and large nprobe: the three row modes of k_select_mfma (scores in registers up to 4096 lists, LDS row up
+    to 16384, global row beyond), shortlists past 512 entries (bitonic sort instead of the rank sort), lists of 0-3
+    vectors."""
+    rng = np.random.default_rng(seed)
+    nlist = int(rng.choice([300, 1000, 3000, 4096, 4097, 6000, 12000, 16384, 16385, 20000]))
+    dim = int(rng.choice([16, 32, 64, 128]))
+    n = int(nlist * rng.choice([1, 2, 4]) + rng.integers(0, 500))
+    nprobe = int(min(nlist, rng.choice([1, 7, 64, 128, 255, 256, 257, 300, 600, 1000, 2048])))
+    return dict(nlist=nlist, dim=dim, n=n, nprobe=nprobe, bits=int(rng.choice([1, 3, 7])), metric=int(rng.integers(0, 2)),
+                rot=int(rng.integers(0, 4) != 0), nq=int(rng.integers(1, 24)), top_k=int(rng.choice([1, 10, 64, 100])))
+
+
+def run_lists(seed):
+    import rabitq_rs_amd as rq
+    c = lists_case(seed)
+    data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
+                                       rotator=c["rot"], seed=seed, normalize=(c["metric"] == 1))
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = conftest.make_dataset(c["nq"], c["dim"], max(c["nlist"] // 4, 1), seed + 1000, normalize=(c["metric"] == 1))
+    ids, sc, cnt = t._compare(built, idx, q, c["top_k"], c["nprobe"])
+    stats["queries"] += len(q)
+    stats["results"] += int(cnt.sum())
+    stats["fallbacks"] = stats.get("fallbacks", 0) + int(idx.rank_fallbacks())
     idx.close()
 
 
@@ -187,7 +215,9 @@ bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        if ties_mode:
+        if lists_mode:
+            run_lists(seed)
+        elif ties_mode:
             run_ties(seed)
         elif mstg_mode:
             run_mstg(seed)
@@ -201,10 +231,10 @@ for seed in range(first, last):
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, (ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, (lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, (ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, (lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
         if os.environ.get("SOAK_TB"):
             traceback.print_exc()
         harness.append(msg)
