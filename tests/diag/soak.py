@@ -14,7 +14,8 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
-wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties", "lists")
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties", "lists", "threads")
+threads_mode = len(sys.argv) > 3 and sys.argv[3] == "threads"
 lists_mode = len(sys.argv) > 3 and sys.argv[3] == "lists"
 ties_mode = len(sys.argv) > 3 and sys.argv[3] == "ties"
 mstg_mode = len(sys.argv) > 3 and sys.argv[3] == "mstg"
@@ -122,6 +123,57 @@ def run_lists(seed):
     idx.close()
 
 
+def threads_case(seed):
+    """One handle, three caller threads inside rbq_search_batch at the same time, each with its own batch size, top_k
+    and nprobe (the handle is re-entrant: every call takes a workspace and a stream from the pool)."""
+    rng = np.random.default_rng(seed)
+    dim = int(rng.choice([64, 128, 384, 960]))
+    nlist = int(rng.integers(8, 200))
+    n = int(rng.integers(nlist * 8, max(nlist * 8 + 1, min(40000, 8_000_000 // dim))))
+    calls = [dict(nq=int(rng.choice([1, 3, 17, 64, 200, 700])), top_k=int(rng.choice([1, 10, 64, 100])),
+                  nprobe=int(rng.integers(1, nlist + 1))) for _ in range(3)]
+    return dict(dim=dim, nlist=nlist, n=n, bits=int(rng.choice([1, 3, 7])), metric=int(rng.integers(0, 2)), calls=calls)
+
+
+def run_threads(seed):
+    import threading
+    import rabitq_rs_amd as rq
+    c = threads_case(seed)
+    data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
+                                       rotator=1, seed=seed, normalize=(c["metric"] == 1))
+    idx = rq.IvfRabitqIndex.from_built(built)
+    qs = [conftest.make_dataset(k["nq"], c["dim"], max(c["nlist"] // 4, 1), seed + 1000 + i, normalize=(c["metric"] == 1))
+          for i, k in enumerate(c["calls"])]
+    want = [oracle.search_batch(built, qs[i], k["top_k"], k["nprobe"]) for i, k in enumerate(c["calls"])]
+    got = [None] * 3
+    errs = []
+
+    def work(i):
+        try:
+            k = c["calls"][i]
+            for _ in range(4):
+                got[i] = idx.batch_search_raw(qs[i], rq.SearchParams(k["top_k"], k["nprobe"]))
+                ids, sc, cnt = got[i][:3]
+                rc, oids, osc, ocnt = want[i][:4]
+                assert rc == 0 and np.array_equal(cnt, ocnt), "counts differ (thread %d)" % i
+                assert np.array_equal(ids, oids), "ids differ (thread %d)" % i
+                for qi in range(len(qs[i])):
+                    kk = int(cnt[qi])
+                    np.testing.assert_allclose(sc[qi, :kk], osc[qi, :kk], rtol=t.RTOL, atol=0)
+        except BaseException as e:  # re-raised in the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if errs:
+        raise errs[0]
+    stats["queries"] += 4 * sum(k["nq"] for k in c["calls"])
+    idx.close()
+
+
 def mstg_case(seed):
     rng = np.random.default_rng(seed)
     return dict(metric=int(rng.integers(0, 2)), bits=int(rng.choice([1, 3, 7])),
@@ -204,6 +256,12 @@ def run_wide(seed):
         if allowed.size:
             np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
     ids, sc, cnt = t._compare(built, idx, q, c["top_k"], c["nprobe"], words, nbits)
+    if words is not None:
+        # without the diagnostic counters a filtered search keeps the block-level bound (k_scan: bound_ok): same results
+        ids2, sc2, cnt2 = idx.batch_search_raw(q, rq.SearchParams(c["top_k"], c["nprobe"]), words, nbits)[:3]
+        assert np.array_equal(cnt2, cnt), "counts differ (filtered, no diagnostics)"
+        assert np.array_equal(ids2, ids), "ids differ (filtered, no diagnostics)"
+        assert np.array_equal(sc2.view(np.uint32), sc.view(np.uint32)), "scores differ (filtered, no diagnostics)"
     idx.close()
     stats["queries"] += len(q)
     stats["results"] += int(cnt.sum())
@@ -215,7 +273,9 @@ bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        if lists_mode:
+        if threads_mode:
+            run_threads(seed)
+        elif lists_mode:
             run_lists(seed)
         elif ties_mode:
             run_ties(seed)
@@ -231,10 +291,10 @@ for seed in range(first, last):
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, (lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, (threads_case(seed) if threads_mode else lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, (lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, (threads_case(seed) if threads_mode else lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
         if os.environ.get("SOAK_TB"):
             traceback.print_exc()
         harness.append(msg)
