@@ -43,7 +43,9 @@ def wide_case(seed):
     short = bool(rng.integers(0, 2))
     enc = bool(rng.integers(0, 3) == 0)
     rbq1 = (not enc) and bool(rng.integers(0, 3) == 0)  # through save_rbq1 -> rbq_index_load_rbq1
-    return dict(rbq1=rbq1, n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, rot=rot, nq=nq, top_k=top_k, nprobe=nprobe,
+    raw_ip = bool(rng.integers(0, 3) == 0)    # inner product over vectors that are NOT normalised
+    uniform = bool(rng.integers(0, 6) == 0)   # all-positive uniform data instead of the mixture
+    return dict(raw_ip=raw_ip, uniform=uniform, rbq1=rbq1, n=n, dim=dim, nlist=nlist, bits=bits, metric=metric, rot=rot, nq=nq, top_k=top_k, nprobe=nprobe,
                 filt=filt, short=short, enc=enc)
 
 
@@ -229,8 +231,9 @@ def run_streams(seed):
 def run_wide(seed):
     import rabitq_rs_amd as rq
     c = wide_case(seed)
+    norm = c["metric"] == 1 and not c["raw_ip"]
     data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
-                                       rotator=c["rot"], seed=seed, normalize=(c["metric"] == 1))
+                                       rotator=c["rot"], seed=seed, normalize=norm, uniform=c["uniform"])
     if c["enc"]:
         import torch
         # build_index clusters internally; redo the clustering here so that the assignment is known
@@ -243,7 +246,7 @@ def run_wide(seed):
         idx = rq.IvfRabitqIndex.load_from_bytes(built.save_rbq1())
     else:
         idx = rq.IvfRabitqIndex.from_built(built)
-    q = conftest.make_dataset(c["nq"], c["dim"], max(c["nlist"] // 4, 1), seed + 1000, normalize=(c["metric"] == 1))
+    q = conftest.make_dataset(c["nq"], c["dim"], max(c["nlist"] // 4, 1), seed + 1000, normalize=norm, uniform=c["uniform"])
     words, nbits = None, 0
     if c["filt"] > 0.0:
         rng = np.random.default_rng(seed + 5)
