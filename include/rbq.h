@@ -47,7 +47,8 @@ extern "C" {
 /* FASTSCAN_BATCH_SIZE, src/simd.rs:768 */
 #define RBQ_BATCH 32
 
-typedef struct rbq_index rbq_index; /* opaque; owns device memory */
+typedef struct rbq_index rbq_index;     /* opaque; owns device memory on one or N GPUs (replicas of one index) */
+typedef struct rbq_builder rbq_builder; /* opaque; an index under construction by the streamed GPU encoder   */
 
 /* Mirrors the scalar fields of `IvfRabitqIndex` (src/ivf.rs:935-946) and the
  * RBQ1-v3 header (src/ivf.rs:1324-1373). */
@@ -87,9 +88,12 @@ typedef struct {
     uint64_t extended_evaluations;
 } rbq_diag;
 
-/* Build a device-resident index from ClusterData-shaped host arrays.
- * n_devices must be 1 in this version; devices[0] is the HIP device ordinal
- * (NULL = current device). Inputs are copied; nothing is retained. */
+/* Build a device-resident index from ClusterData-shaped host arrays.  The reference bytes are uploaded as they
+ * are and re-laid into the device layout by the GPU.
+ * n_devices >= 1 replicas: devices[i] = HIP device ordinal of replica i (NULL = the current device for one
+ * replica, devices 0..n-1 otherwise; an ordinal may repeat).  Replica 0 is built from the host arrays, the others
+ * are device-to-device copies of it.  `rbq_search_batch` shards a batch over the replicas (the reference's
+ * batch_search is a par_iter over queries, src/ivf.rs:1743-1752).  Inputs are copied; nothing is retained. */
 int rbq_index_create(const rbq_header* hdr, const rbq_list_view* lists,
                      int n_devices, const int* devices, rbq_index** out);
 
@@ -113,6 +117,27 @@ int rbq_index_load_rbq1(const void* bytes, size_t len,
 int rbq_index_build_device(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
                            uint64_t n, float t_const, int device, rbq_index** out);
 
+/* The same encoder fed chunk by chunk, for indexes whose raw vectors do not fit in HBM at once (100 M x 768 f32 =
+ * 307 GB): `train_with_clusters` (src/ivf.rs:1025-1215) builds cluster by cluster and never needs all vectors
+ * resident either.  Protocol:
+ *   begin   hdr / centroids / t_const as for rbq_index_build_device; list_sizes HOST [n_lists] = number of vectors
+ *           each cluster will receive (the caller's count pass over its assignment).  All device arrays of the
+ *           index are allocated here.
+ *   push    `count` vectors with ids first_id .. first_id+count-1 and their cluster ids.  vectors [count][dim] f32
+ *           and assign [count] u32 may each be HOST or DEVICE pointers (detected).  Chunks must arrive in ascending
+ *           id order (list membership order = ascending vector index, src/ivf.rs:1141-1149).  A list that receives
+ *           more vectors than announced, or an id out of range, is RBQ_INVALID_CONFIG; after an error the builder
+ *           can only be aborted.
+ *   finish  requires every announced vector to have been pushed; returns the index (identical, array for array,
+ *           to rbq_index_build_device over the same data), replicated on n_devices (devices[0] must be the
+ *           builder's device; NULL / 1 = that device only) and frees the builder.
+ *   abort   frees a builder that was not finished. */
+int rbq_build_stream_begin(const rbq_header* hdr, const float* centroids, const uint32_t* list_sizes, float t_const,
+                           int device, rbq_builder** out);
+int rbq_build_stream_push(rbq_builder* b, const float* vectors, const uint32_t* assign, uint64_t first_id, uint64_t count);
+int rbq_build_stream_finish(rbq_builder* b, int n_devices, const int* devices, rbq_index** out);
+void rbq_build_stream_abort(rbq_builder* b);
+
 void rbq_index_destroy(rbq_index* idx);
 
 /* Accessors (IvfRabitqIndex::len / cluster_count, src/ivf.rs:1218-1230). */
@@ -120,6 +145,7 @@ uint64_t rbq_index_len(const rbq_index* idx);
 uint64_t rbq_index_cluster_count(const rbq_index* idx);
 uint32_t rbq_index_dim(const rbq_index* idx);
 uint32_t rbq_index_padded_dim(const rbq_index* idx);
+uint32_t rbq_index_device_count(const rbq_index* idx); /* number of replicas */
 
 /* `batch_search` (src/ivf.rs:1743-1752); nq = 1 is `search` (:1705);
  * filter_words != NULL is `search_filtered` (:1723): a dense bitset over the
@@ -134,7 +160,12 @@ uint32_t rbq_index_padded_dim(const rbq_index* idx);
  * Errors follow search_fastscan: EMPTY_INDEX is checked before
  * DIMENSION_MISMATCH (src/ivf.rs:1761-1769); top_k == 0 returns RBQ_OK with all
  * counts 0 (:1792-1794); nprobe is clamped to [1, n_lists] (:1791).
- * Re-entrant on one handle. */
+ * Limits of this version (the reference has none): after the clamp nprobe <= 4096 and top_k <= 4096, else
+ * RBQ_INVALID_CONFIG; nq < 2^31 per call of the device entry.
+ * Re-entrant on one handle.  The batch is cut into sub-batches that are pipelined over a few streams: host
+ * staging and PCIe copies of one sub-batch overlap the kernels of the others.  Buffers that are page-locked
+ * (rbq_host_alloc, hipHostMalloc, hipHostRegister) are DMA-ed directly; pageable ones are staged through the
+ * handle's pinned buffers.  With N replicas the queries are split into N contiguous shards, one per device. */
 int rbq_search_batch(const rbq_index* idx, const float* queries, uint64_t nq,
                      uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
                      const uint32_t* filter_words, uint64_t filter_nbits,
@@ -168,6 +199,24 @@ int rbq_search_batch_device(const rbq_index* idx, const float* d_queries, uint64
                             uint32_t* d_out_counts, rbq_diag* d_diag,
                             void* hip_stream);
 
+/* Frees the scratch workspace the handle keeps for `hip_stream` (rbq_search_batch_device creates one per caller
+ * stream and keeps it until the index is destroyed); call it before destroying a stream that will not be used
+ * with this index again.  The stream must be idle. */
+int rbq_release_stream(rbq_index* idx, void* hip_stream);
+
+/* Page-locked host memory for query / result buffers: rbq_search_batch DMA-s such buffers directly. */
+void* rbq_host_alloc(size_t bytes);
+void rbq_host_free(void* p);
+
+/* OPTIONAL full-precision rerank — an extension (BASELINE north_star item 3), NOT reference behaviour: the
+ * reference index stores no raw vectors (src/ivf.rs:207-242) and never re-scores.  Default OFF; results are
+ * reference-identical only while it is off.  `vectors` [n][dim] f32 (HOST: copied to every replica; DEVICE pointer
+ * on the replica's device: borrowed, must outlive the index) indexed by id; passing NULL detaches.  While enabled,
+ * every search re-scores its returned ids with the exact l2_distance_sqr / dot (canonical order of
+ * src/math.rs:154-245) against these vectors and re-sorts them; ids >= n get NaN.  top_k <= 1024.
+ * Toggle with rbq_debug_set_option(idx, "rerank", 0/1) once vectors are attached (attaching switches it on). */
+int rbq_index_set_rerank_vectors(rbq_index* idx, const float* vectors, uint64_t n);
+
 /* Timing taps for bench.py: average duration (ms) of each stage kernel between
  * rbq_profile_begin/end, measured with hipEvents on the stream the kernels run
  * on. stage names: "prep", "rank", "select", "scan". Returns <0 for an unknown stage. */
@@ -177,6 +226,11 @@ double rbq_profile_stage_ms(const rbq_index* idx, const char* stage, uint64_t* l
 /* Algorithmic bytes (sum over probed lists of n_c*(D/8+12)) of the
  * scan launches between rbq_profile_begin/end. */
 uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
+/* Traffic counters of the scan launches between rbq_profile_begin/end (summed over replicas), out[0..n):
+ *   [0] vectors probed (sum of n_c over probed lists)   [1] block records whose sign codes were requested
+ *   [2] block records whose factor rows were requested  [3] block-stream entries read (16 B each)
+ *   [4] ex-code evaluations                             [5] queries scanned                */
+int rbq_profile_counters(const rbq_index* idx, uint64_t* out, uint32_t n);
 /* Which stages rbq_profile_begin/end time: bit 0 prep, 1 rank, 2 select, 3 scan (default: all four). Every timed
  * stage costs two event records per launch; a throughput measurement that only needs the dominant kernel's
  * duration selects that stage alone. */
@@ -202,7 +256,10 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *   "force_rank_fallback" 1   send every query through the shortlist's all-lists fallback
  *   "f32_rank" 1         approximate list scores from the f32 MFMA GEMM instead of the split-bf16 one
  *   "wg_prep" 1          workgroup-per-query query preparation for every rotator (default: one wave per query)
- *   "exact_heap" 1       keep the top-k in the BinaryHeap emulation from the first candidate (no sorted fast path) */
+ *   "exact_heap" 1       keep the top-k in the BinaryHeap emulation from the first candidate (no sorted fast path)
+ * and two that are not result-neutral:
+ *   "rerank" 0/1         the optional full-precision rerank (needs rbq_index_set_rerank_vectors)
+ *   "debug_replica" r    which replica rbq_debug_copy_index / rbq_debug_copy_workspace read */
 int rbq_debug_set_option(rbq_index* idx, const char* name, int value);
 
 const char* rbq_strerror(int code);

@@ -64,8 +64,8 @@ class SearchResult:
     score: float
 
 
-from .index import IvfRabitqIndex  # noqa: E402
+from .index import IvfRabitqIndex, StreamBuilder  # noqa: E402
 from . import builder  # noqa: E402,F401
 
 __all__ = ["Metric", "RotatorType", "RabitqError", "SearchParams", "SearchResult", "IvfRabitqIndex",
-           "builder"]
+           "StreamBuilder", "builder"]

@@ -17,8 +17,6 @@
 
 namespace rbq {
 
-constexpr uint32_t kNoSrc = 0xffffffffu;
-
 // rows[r] = rotate(src[map ? map[r] : r]) for r < nrows; rows of padding slots (map[r] == kNoSrc) are skipped
 __global__ __launch_bounds__(kThreads) void k_rotate_rows(const float* __restrict__ src, const uint32_t* __restrict__ map,
                                                           uint32_t dim, uint32_t D, int rotator,
@@ -34,22 +32,6 @@ __global__ __launch_bounds__(kThreads) void k_rotate_rows(const float* __restric
     for (uint32_t i = tid; i < D; i += kThreads) rows[(size_t)r * D + i] = x[i];
 }
 
-struct EncodeParams {
-    const float* rows;          // [nslots][D] rotated vectors of this chunk (slot-local order)
-    const float* centroids;     // [nlist][D] rotated
-    const uint32_t* slot_src;   // [nslots] source vector index or kNoSrc (chunk-local view)
-    const uint32_t* block_list; // [nblocks] list of every block (chunk-local view)
-    uint8_t* blocks;            // chunk-local view of the block records
-    uint8_t* raw_ex;            // [nslots][D] u8 scratch (ex_bits > 0)
-    float* f_add_ex;            // chunk-local views
-    float* f_rescale_ex;
-    uint64_t* ids;
-    uint64_t src_base;          // ids[slot] = src_base + source index
-    uint32_t nslots, D, Dc, ex_bits, metric;
-    float t_const;
-};
-
-constexpr int kEncThreads = 64;          // 64 vectors = 2 blocks per workgroup
 constexpr int kEncTile = 64;             // dims per LDS tile
 constexpr int kEncLd = kEncTile + 1;     // row stride (floats): lane i reads word i*65 + k -> conflict-free
 
@@ -71,16 +53,23 @@ struct Dot8 {
     }
 };
 
+// SCATTER = false: block-ordered chunk (rbq_index_build_device) — row r IS chunk-local slot r, the 32 lanes of a
+//   half-wave share one block and therefore one centroid row.
+// SCATTER = true: streamed build (rbq_build_stream_push) — rows are the chunk's vectors sorted by slot, row r goes
+//   to GLOBAL slot row_slot[r]; every row stages its own centroid tile.  Same arithmetic, expression for expression.
+template <bool SCATTER>
 __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
     __shared__ float s_x[kEncThreads * kEncLd];
-    __shared__ float s_c[2 * kEncTile];
-    const uint32_t tid = threadIdx.x, half = tid >> 5, v = tid & 31u;
-    const uint32_t slot = blockIdx.x * kEncThreads + tid;         // chunk-local slot
-    const uint32_t blk = blockIdx.x * 2 + half;                   // chunk-local block
+    __shared__ float s_c[SCATTER ? kEncThreads * kEncLd : 2 * kEncTile];
+    const uint32_t tid = threadIdx.x, half = tid >> 5;
+    const uint32_t slot = blockIdx.x * kEncThreads + tid;         // row (block-ordered mode: chunk-local slot)
     const uint32_t nblk = (P.nslots + 31u) / 32u;
-    const bool has_blk = blk < nblk;
     const uint32_t src = (slot < P.nslots) ? P.slot_src[slot] : kNoSrc;
     const bool valid = src != kNoSrc;
+    const uint32_t oslot = SCATTER ? (valid ? P.row_slot[slot] : 0u) : slot; // output slot in the views of P
+    const uint32_t blk = SCATTER ? (oslot >> 5) : blockIdx.x * 2 + half;
+    const uint32_t v = SCATTER ? (oslot & 31u) : (tid & 31u);
+    const bool has_blk = SCATTER ? valid : blk < nblk;
     const uint32_t D = P.D, Dc = P.Dc, ex_bits = P.ex_bits;
     const size_t stride = (size_t)Dc * 4 + 384;
     uint8_t* rec = P.blocks + (size_t)blk * stride;
@@ -99,6 +88,18 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
             float* d = s_x + r * kEncLd + k4;
             d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
         }
+        if (SCATTER) {
+#pragma unroll 4
+            for (uint32_t it = 0; it < 16; ++it) {
+                const uint32_t r = it * 4 + (tid >> 4), k4 = (tid & 15u) * 4;
+                const uint32_t gs = blockIdx.x * kEncThreads + r;
+                float4 c = make_float4(0, 0, 0, 0);
+                if (gs < P.nslots && k4 < w && P.slot_src[gs] != kNoSrc)
+                    c = *reinterpret_cast<const float4*>(P.centroids + (size_t)P.block_list[P.row_slot[gs] >> 5] * D + t0 + k4);
+                float* d = s_c + r * kEncLd + k4;
+                d[0] = c.x; d[1] = c.y; d[2] = c.z; d[3] = c.w;
+            }
+        } else
         for (uint32_t i = tid; i < 2u * kEncTile; i += kEncThreads) {
             const uint32_t h = i / kEncTile, k = i % kEncTile, b = blockIdx.x * 2 + h;
             s_c[i] = (b < nblk && k < w) ? P.centroids[(size_t)P.block_list[b] * D + t0 + k] : 0.0f;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
     for (uint32_t t0 = 0; t0 < D; t0 += kEncTile) {
         const uint32_t w = stage(t0);
         const float* xr = s_x + tid * kEncLd;
-        const float* cr = s_c + half * kEncTile;
+        const float* cr = SCATTER ? s_c + tid * kEncLd : s_c + half * kEncTile;
         for (uint32_t k0 = 0; k0 < w; k0 += 8) {
             uint32_t byte = 0;
 #pragma unroll
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
         for (uint32_t t0 = 0; t0 < D; t0 += kEncTile) {
             const uint32_t w = stage(t0);
             const float* xr = s_x + tid * kEncLd;
-            const float* cr = s_c + half * kEncTile;
+            const float* cr = SCATTER ? s_c + tid * kEncLd : s_c + half * kEncTile;
             for (uint32_t k0 = 0; k0 < w; k0 += 16) {
                 uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
         fac[v] = valid ? f_add : 0.0f;
         fac[32 + v] = valid ? f_rescale : 0.0f;
         fac[64 + v] = valid ? f_error : 0.0f;
-        const uint32_t s = blk * 32 + v;
+        const uint32_t s = SCATTER ? oslot : blk * 32 + v;
         P.ids[s] = valid ? P.src_base + src : ~0ull;
         if (ex_bits) {
             P.f_add_ex[s] = valid ? f_add_ex : 0.0f;
@@ -241,14 +242,17 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(EncodeParams P) {
 }
 
 // raw ex codes [slot][D] u8 -> [slot][unit][lane][16 B]; 16 lanes per vector, 16 vectors per workgroup
+// (row_slot != null: row `slot` of the raw codes goes to the global slot row_slot[slot] — streamed build)
 __global__ __launch_bounds__(256) void k_pack_ex(const uint8_t* __restrict__ raw, const uint32_t* __restrict__ slot_src,
+                                                 const uint32_t* __restrict__ row_slot,
                                                  uint32_t nslots, uint32_t D, uint32_t ex_bits, uint8_t* __restrict__ ex) {
     const uint32_t slot = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15u;
     if (slot >= nslots) return;
     const uint32_t w4 = ex_w4(D, ex_bits), cpu = ex_cpu(ex_bits);
     const size_t exd = (size_t)w4 * 256;
-    uint4* dst = reinterpret_cast<uint4*>(ex + (size_t)slot * exd) + l;
     const bool valid = slot_src[slot] != kNoSrc;
+    if (row_slot && !valid) return;
+    uint4* dst = reinterpret_cast<uint4*>(ex + (size_t)(row_slot ? row_slot[slot] : slot) * exd) + l;
     const uint8_t* src = raw + (size_t)slot * D + l;
     uint32_t t = 0;
     for (uint32_t unit = 0; unit < w4; ++unit) {

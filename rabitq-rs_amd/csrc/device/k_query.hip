@@ -1,0 +1,113 @@
+// k_query.hip — translation unit of the per-batch query stages in front of the scan: k_prep / k_prep_wave
+// (rotate + constants + LUT), the centroid-ranking GEMMs, probe selection and the MSTG probe list.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include "launch.hpp"
+#include "query_kernels.hpp"
+#include "rank_mfma.hpp"
+
+namespace rbq {
+
+namespace {
+uint32_t next_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+} // namespace
+
+hipError_t launch_prep(const PrepParams& p, int device, hipStream_t s) {
+    if (p.rotator == 0 /* matrix: O(D^2) per query */ || p.wg_prep) {
+        static LdsAttrCache attr;
+        const size_t lds = (size_t)p.D * 4 * 2;
+        hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_prep), lds, device);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prep, dim3(p.nq), dim3(kThreads), lds, s, p.queries, p.dim, p.D, p.Dc, p.rotator, p.rot_blob, p.trunc,
+                           p.fac, p.ex_bits, p.rot, p.lut, p.consts, p.rot_hi, p.rot_lo);
+    } else { // FHT-Kac / identity: one wave per query
+        static LdsAttrCache attr;
+        const uint32_t qpw = kThreads / 64;
+        const size_t lds = (size_t)p.D * 4 * 2 * qpw + p.D / 2;
+        hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_prep_wave), lds, device); // 66.5 KB at D = 2048
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_prep_wave, dim3((p.nq + qpw - 1) / qpw), dim3(kThreads), lds, s, p.queries, p.nq, p.dim, p.D, p.Dc,
+                           p.rotator, p.rot_blob, p.trunc, p.fac, p.ex_bits, p.rot, p.lut, p.consts, p.rot_hi, p.rot_lo);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_exact(const RankParams& p, hipStream_t s) {
+    dim3 grid((p.nlist + 31) / 32, (p.nq + 31) / 32);
+    if (p.metric == 0) hipLaunchKernelGGL(k_rank_scores<0>, grid, dim3(kThreads), 0, s, p.rot, p.cent, p.nq, p.nlist, p.D, p.scores);
+    else hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, s, p.rot, p.cent, p.nq, p.nlist, p.D, p.scores);
+    return hipGetLastError();
+}
+
+namespace {
+// big problems: 128x128 tiles, 8 waves (each 64x32) — the tile traffic of the 4-wave form with twice the waves to
+// hide the staging behind the MFMAs; small ones: 64x64 tiles, 4 waves
+template <int M, int TM, int TN, int WM, int WN>
+hipError_t launch_rank_split(const RankParams& p, dim3 grid, int device, hipStream_t s) {
+    static LdsAttrCache attr;
+    const size_t lds = (size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 80 * 2; // two slabs of 32, rows of 80 B
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_rank_bf16_db<M, TM, TN, WM, WN>), lds, device);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_rank_bf16_db<M, TM, TN, WM, WN>), grid, dim3(64 * WM * WN), lds, s, p.rot_hi, p.rot_lo, p.cent_hi, p.cent_lo,
+                       p.consts, p.cnorm2, p.nq, p.nlist, p.D, p.scores);
+    return hipGetLastError();
+}
+template <int M, int TW>
+hipError_t launch_rank_f32(const RankParams& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_rank_mfma<M, TW>), grid, dim3(256), 0, s, p.rot, p.cent, p.consts, p.cnorm2, p.nq, p.nlist, p.D, p.scores);
+    return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s) {
+    const uint32_t T = p.big ? 128u : 64u;
+    dim3 grid((p.nlist + T - 1) / T, (p.nq + T - 1) / T);
+    if (p.split) {
+        if (p.metric == 0) return p.big ? launch_rank_split<0, 2, 1, 2, 4>(p, grid, device, s) : launch_rank_split<0, 1, 1, 2, 2>(p, grid, device, s);
+        return p.big ? launch_rank_split<1, 2, 1, 2, 4>(p, grid, device, s) : launch_rank_split<1, 1, 1, 2, 2>(p, grid, device, s);
+    }
+    if (p.metric == 0) return p.big ? launch_rank_f32<0, 2>(p, grid, s) : launch_rank_f32<0, 1>(p, grid, s);
+    return p.big ? launch_rank_f32<1, 2>(p, grid, s) : launch_rank_f32<1, 1>(p, grid, s);
+}
+
+hipError_t launch_select_exact(const SelectParams& p, hipStream_t s) {
+    const uint32_t np2 = next_pow2(p.nprobe);
+    const size_t lds = (size_t)np2 * 8 + (size_t)p.D * 4 + kThreads * 4;
+    hipLaunchKernelGGL(k_select, dim3(p.nq), dim3(kThreads), lds, s, (const float*)p.scores, p.nlist, p.nprobe, np2, p.metric, p.rot,
+                       p.cent, p.D, p.list_gb0, p.list_n, p.probe, p.wl, p.wl_stride, p.nstream, p.nvec, p.prof_total, p.consts,
+                       p.bsum);
+    return hipGetLastError();
+}
+
+namespace {
+template <int RM>
+hipError_t launch_select_rm(const SelectParams& p, uint32_t cap2, int row_in_lds, size_t lds, int stage, int device, hipStream_t s) {
+    static LdsAttrCache attr;
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_select_mfma<RM>), lds, device);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_select_mfma<RM>, dim3(p.nq), dim3(kThreads), lds, s, p.scores, p.nlist, p.nprobe, cap2, row_in_lds, p.metric,
+                       p.rot, p.cent, p.D, p.consts, p.cnorm2_max, p.list_gb0, p.list_n, p.probe, p.wl, p.wl_stride, p.nstream,
+                       p.nvec, p.prof_total, p.fallback_count, p.force_fallback, p.bsum, stage);
+    return hipGetLastError();
+}
+} // namespace
+
+hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) {
+    const uint32_t cap2 = next_pow2(2 * p.nprobe) < 64u ? 64u : next_pow2(2 * p.nprobe);
+    const int row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536) ? 1 : 0; // <= 4096: registers
+    size_t lds = (size_t)cap2 * 8 + (size_t)p.D * 4 + kThreads * 4 + (row_in_lds ? (size_t)p.nlist * 4 : 0);
+    const int stage = lds + (size_t)p.nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
+    if (stage) lds += (size_t)p.nprobe * 16;
+    if (p.nlist <= 4096) return launch_select_rm<2>(p, cap2, row_in_lds, lds, stage, device, s);
+    if (row_in_lds) return launch_select_rm<1>(p, cap2, row_in_lds, lds, stage, device, s);
+    return launch_select_rm<0>(p, cap2, row_in_lds, lds, stage, device, s);
+}
+
+hipError_t launch_probes_given(const ProbesGivenParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(k_probes_given, dim3(p.nq), dim3(kThreads), (size_t)p.D * 4 + kThreads * 4, s, p.list_ids, p.list_counts,
+                       p.max_lists, p.nlist, p.metric, p.rot, p.cent, p.D, p.list_gb0, p.list_n, p.probe, p.wl, p.wl_stride, p.nstream,
+                       p.consts, p.bsum);
+    return hipGetLastError();
+}
+
+} // namespace rbq

@@ -1,0 +1,51 @@
+// k_scan.hip — translation unit of the roofline kernel (scan.hpp) and its launcher.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "launch.hpp"
+#include "scan.hpp"
+
+namespace rbq {
+
+hipError_t LdsAttrCache::ensure(const void* fn, size_t lds, int device) {
+    if (lds <= 48 * 1024) return hipSuccess; // default dynamic-LDS limit
+    const int d = device & 15;
+    if (lds <= set[d]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) set[d] = lds; // (a racing caller at worst repeats the call)
+    return e;
+}
+
+namespace {
+
+template <int DT, int EX>
+hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    static LdsAttrCache attr;
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_scan<DT, EX>), lds, device);
+    if (e != hipSuccess) return e;
+    if (ev0) hipExtLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, ev0, ev1, 0, P);
+    else hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
+    return hipGetLastError();
+}
+template <int DT>
+hipError_t launch_scan_d(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (DT == 0) return launch_scan_t<0, 0>(P, nq, lds, device, s, ev0, ev1);
+    switch (P.ex_bits) {
+        case 0: return launch_scan_t<DT, 0>(P, nq, lds, device, s, ev0, ev1);
+        case 2: return launch_scan_t<DT, 2>(P, nq, lds, device, s, ev0, ev1);
+        default: return launch_scan_t<DT, 6>(P, nq, lds, device, s, ev0, ev1);
+    }
+}
+
+} // namespace
+
+hipError_t launch_scan(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    const uint32_t D = P.D, Dc = P.Dc;
+    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, P.top_k);
+    if (D == Dc && D == 960) return launch_scan_d<960>(P, nq, lds, device, s, ev0, ev1);
+    if (D == Dc && D == 768) return launch_scan_d<768>(P, nq, lds, device, s, ev0, ev1);
+    if (D == Dc && D == 128) return launch_scan_d<128>(P, nq, lds, device, s, ev0, ev1);
+    return launch_scan_d<0>(P, nq, lds, device, s, ev0, ev1);
+}
+
+} // namespace rbq

@@ -16,39 +16,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "types.hpp"
 
 namespace rbq {
 
-constexpr int kThreads = 256;
-
-struct QueryConsts {
-    float delta, sum_vl, k1x, kbx, scale, qnorm;
-    float qnorm2, pad0, pad1, pad2; // |q|^2 of the rotated query (approximate ranking, rank_mfma.hpp)
-    float amin, amax; // sum over codebooks of the smallest / largest u8 entry: accu of ANY code lies in [amin, amax]
-};
-struct ProbeInfo {
-    float g_add, g_err, dotqc;
-    uint32_t cid;
-};
-struct WorkItem {
-    uint32_t gblock;      // global 32-vector block index
-    uint32_t rank_nvalid; // (probe rank << 6) | number of real vectors in the block (1..32)
-};
-// Per-block factor ranges over the block's REAL vectors, computed once at index creation.  Every float op of
-// the epilogue is monotone in each operand, so evaluating it on these extremes brackets every lane's lower
-// bound: lbmin <= lb_v <= lbmax.  `usable` is 0 when any factor is non-finite (the block is then never skipped).
-struct BlockSummary {
-    float fadd_min, fadd_max, fres_min, fres_max, ferr_min, ferr_max;
-    uint32_t usable, pad;
-};
-// One entry of a query's block stream (probe order, block order within a list).  `lbmin` is the block-level
-// lower bound of this (query, block) pair — everything in it but the running threshold is known when the
-// stream is written, so the scan's fill step is one 16-byte load and one compare per block.
-struct StreamItem {
-    uint32_t gblock, rank_nvalid;
-    float lbmin; // -inf: never skip
-    uint32_t pad;
-};
 // Block-level bound: accu of any code lies in [amin, amax] and lb is monotone in accu (direction = sign of
 // f_rescale), so the epilogue's own operation sequence (compute_batch_distances_u16, AVX2 body: only the first
 // op is fused) evaluated on the extremes of every operand is <= lb of every real vector of the block.
@@ -131,26 +102,6 @@ __device__ __forceinline__ void fht_lds(float* a, uint32_t n, uint32_t tid) {
     }
 }
 
-// round-to-nearest-even f32 -> bf16 bits (inf stays inf; NaN stays NaN)
-__host__ __device__ inline uint16_t bf16_rne(float x) {
-    uint32_t u;
-    __builtin_memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u); // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-__host__ __device__ inline float bf16_to_f32(uint16_t h) {
-    uint32_t u = (uint32_t)h << 16;
-    float f;
-    __builtin_memcpy(&f, &u, 4);
-    return f;
-}
-// x = hi + lo + r: the subtraction is exact (hi is x rounded to 8 significant bits)
-__host__ __device__ inline void bf16_split(float x, uint16_t& hi, uint16_t& lo) {
-    hi = bf16_rne(x);
-    lo = bf16_rne(x - bf16_to_f32(hi));
-}
-
 // Rotator::rotate_into for one vector, by GS threads (one workgroup or one wave): the rotated vector ends up in x[0..D)
 // (LDS); y[0..D) is scratch for the matrix rotator.  Butterflies/adds are the reference's, stage by stage
 // (src/rotation.rs:248-401), so the result is bit-identical to the CPU path.
@@ -214,509 +165,6 @@ __device__ __forceinline__ void rotate_into_lds(float* x, float* y, const float*
 
 }
 
-__global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ queries, uint32_t dim, uint32_t D,
-                                                   uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
-                                                   uint32_t trunc, float fac, uint32_t ex_bits,
-                                                   float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
-                                                   QueryConsts* __restrict__ consts,
-                                                   uint16_t* __restrict__ rot_hi, uint16_t* __restrict__ rot_lo) {
-    extern __shared__ __align__(16) float sm[];
-    float* x = sm;         // [D]
-    float* y = sm + D;     // [D] (matrix rotator input)
-    __shared__ int s_kmin, s_kmax;
-    __shared__ unsigned int s_amin, s_amax;
-    __shared__ float s_sum, s_n2;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const float* qin = queries + (size_t)q * dim;
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
-#endif
-
-    rotate_into_lds<kThreads>(x, y, qin, dim, D, rotator, rot_blob, trunc, fac, tid);
-
-    for (uint32_t i = tid; i < D; i += kThreads) {
-        rot_out[(size_t)q * D + i] = x[i];
-        if (rot_hi) { // split-bf16 image for k_rank_bf16_db
-            uint16_t h, l;
-            bf16_split(x[i], h, l);
-            rot_hi[(size_t)q * D + i] = h;
-            rot_lo[(size_t)q * D + i] = l;
-        }
-    }
-
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
-#endif
-    // QueryPrecomputed::new — strictly sequential sums (Rust iter().sum() folds from -0.0)
-    if (tid == 0) {
-        float s = -0.0f;
-        for (uint32_t i = 0; i < D; ++i) s = s + x[i];
-        s_sum = s;
-        s_kmin = 0x7fffffff;
-        s_kmax = (int)0x80000000;
-        s_amin = 0;
-        s_amax = 0;
-    }
-    if (tid == 64) {
-        float n2 = -0.0f;
-        for (uint32_t i = 0; i < D; ++i) {
-            float p = x[i] * x[i];
-            n2 = n2 + p;
-        }
-        s_n2 = n2;
-    }
-    __syncthreads();
-
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
-#endif
-    // pack_lut_f32 + QueryLut::new.  D <= 2048 -> at most 2 codebooks per thread.
-    const uint32_t ncb = D / 4;
-    float l[2][16];
-    int kmin = 0x7fffffff, kmax = (int)0x80000000;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        uint32_t c = tid + u * kThreads;
-        if (c < ncb) {
-            const float q0 = x[4 * c], q1 = x[4 * c + 1], q2 = x[4 * c + 2], q3 = x[4 * c + 3];
-            // lut[j] = lut[j - lowbit(j)] + q[KPOS[j]],  KPOS = {3,3,2,3,1,3,2,3,0,3,2,3,1,3,2,3}
-            l[u][0] = 0.0f;
-            l[u][1] = l[u][0] + q3;
-            l[u][2] = l[u][0] + q2;
-            l[u][3] = l[u][2] + q3;
-            l[u][4] = l[u][0] + q1;
-            l[u][5] = l[u][4] + q3;
-            l[u][6] = l[u][4] + q2;
-            l[u][7] = l[u][6] + q3;
-            l[u][8] = l[u][0] + q0;
-            l[u][9] = l[u][8] + q3;
-            l[u][10] = l[u][8] + q2;
-            l[u][11] = l[u][10] + q3;
-            l[u][12] = l[u][8] + q1;
-            l[u][13] = l[u][12] + q3;
-            l[u][14] = l[u][12] + q2;
-            l[u][15] = l[u][14] + q3;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int k = total_key(l[u][j]);
-                kmin = k < kmin ? k : kmin;
-                kmax = k > kmax ? k : kmax;
-            }
-        }
-    }
-    atomicMin(&s_kmin, kmin);
-    atomicMax(&s_kmax, kmax);
-    __syncthreads();
-    const float vl = key_to_float(s_kmin), vr = key_to_float(s_kmax);
-    const float delta = (vr - vl) / 255.0f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        uint32_t c = tid + u * kThreads;
-        if (c < ncb) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            uint32_t emin = 255, emax = 0;
-            if (delta > 0.0f) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float v = roundf((l[u][j] - vl) / delta);
-                    v = v >= 0.0f ? v : 0.0f; // also maps NaN -> 0 like `as u8`
-                    v = v > 255.0f ? 255.0f : v;
-                    const uint32_t e = (uint32_t)v;
-                    emin = e < emin ? e : emin;
-                    emax = e > emax ? e : emax;
-                    w[j >> 2] |= e << (8 * (j & 3));
-                }
-            } else {
-                emin = 0;
-            }
-            atomicAdd(&s_amin, emin);
-            atomicAdd(&s_amax, emax);
-            // device LUT order: adjacent codebooks swapped (position p holds codebook p^1) so that
-            // nibble m of a little-endian code dword indexes table (8*dword + m) directly.
-            uint4* dst = reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16);
-            *dst = make_uint4(w[0], w[1], w[2], w[3]);
-        } else if (c < Dc / 4) { // code-layout padding (D not a multiple of 64): all-zero tables
-            uint4* dst = reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16);
-            *dst = make_uint4(0, 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        QueryConsts qc;
-        qc.amin = (float)s_amin;
-        qc.amax = (float)s_amax;
-        qc.delta = delta;
-        qc.sum_vl = vl * (float)(D / 4);
-        qc.qnorm = sqrtf(s_n2);
-        qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
-#ifdef RBQ_PREP_STAMPS
-        qc.pad0 = (float)(pt1 - pt0); qc.pad1 = (float)(pt2 - pt1); qc.pad2 = (float)(__builtin_amdgcn_s_memtime() - pt2);
-#endif
-        qc.k1x = -0.5f * s_sum;
-        const float cb = -((float)(1u << ex_bits) - 0.5f);
-        qc.kbx = cb * s_sum;
-        qc.scale = (float)(1u << ex_bits);
-        consts[q] = qc;
-    }
-}
-
-// In-register FHT of one wave over n = 64*EPL floats at `part` (LDS): lane holds elements lane*EPL .. +EPL-1, so
-// the stages h < EPL are register butterflies and the stages h = EPL*m (m = 1..32) exchange with lane ^ m.  Same
-// butterflies in the same stage order as fht_lds (out[j] = x[j] + x[j+h], out[j+h] = x[j] - x[j+h]), followed by
-// the reference's rescale x * fac.
-template <int EPL>
-__device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) {
-    float v[EPL];
-    if (EPL >= 4) {
-#pragma unroll
-        for (int k = 0; k < EPL; k += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(part + lane * EPL + k);
-            v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) v[k] = part[lane * EPL + k];
-    }
-#pragma unroll
-    for (int h = 1; h < EPL; h <<= 1)
-#pragma unroll
-        for (int k = 0; k < EPL; ++k)
-            if ((k & h) == 0) {
-                const float a = v[k], b = v[k + h];
-                v[k] = a + b;
-                v[k + h] = a - b;
-            }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const bool upper = (lane & (uint32_t)m) != 0;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            const float p = __shfl_xor(v[k], m, 64);
-            v[k] = upper ? (p - v[k]) : (v[k] + p);
-        }
-    }
-    if (EPL >= 4) {
-#pragma unroll
-        for (int k = 0; k < EPL; k += 4)
-            *reinterpret_cast<float4*>(part + lane * EPL + k) = make_float4(v[k] * fac, v[k + 1] * fac, v[k + 2] * fac, v[k + 3] * fac);
-    } else {
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) part[lane * EPL + k] = v[k] * fac;
-    }
-}
-
-// FhtKacRotator::rotate_into by one wave; `flips` = the 4*D/8 flip-sign bytes (LDS copy).  Same operations as
-// rotate_into_lds<64>, with fht_wave in place of the LDS butterflies.
-template <int EPL>
-__device__ __forceinline__ void rotate_fhtkac_wave(float* x, const float* __restrict__ qin, uint32_t dim, uint32_t D,
-                                                   const uint8_t* flips, float fac, uint32_t lane) {
-    constexpr uint32_t trunc = 64u * EPL;
-    for (uint32_t i = lane; i < D; i += 64) x[i] = i < dim ? qin[i] : 0.0f;
-    group_sync<64>();
-    const uint32_t fo = D / 8, start = D - trunc, half = D / 2;
-    for (int r = 0; r < 4; ++r) {
-        const uint8_t* f = flips + r * fo;
-        for (uint32_t i = lane; i < D; i += 64)
-            if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
-        group_sync<64>();
-        fht_wave<EPL>((trunc != D && (r & 1)) ? x + start : x, lane, fac);
-        group_sync<64>();
-        if (trunc != D) {
-            for (uint32_t i = lane; i < half; i += 64) {
-                const float a = x[i], b = x[i + half];
-                x[i] = a + b;
-                x[i + half] = a - b;
-            }
-            group_sync<64>();
-        }
-    }
-    if (trunc != D) {
-        for (uint32_t i = lane; i < D; i += 64) x[i] = x[i] * 0.25f;
-        group_sync<64>();
-    }
-}
-
-// pack_lut_f32 entries of one codebook: lut[j] = lut[j - lowbit(j)] + q[KPOS[j]],  KPOS = {3,3,2,3,1,3,2,3,0,3,2,3,1,3,2,3}
-__device__ __forceinline__ void lut_entries(const float* x4, float (&l)[16]) {
-    const float q0 = x4[0], q1 = x4[1], q2 = x4[2], q3 = x4[3];
-    l[0] = 0.0f;
-    l[1] = l[0] + q3;
-    l[2] = l[0] + q2;
-    l[3] = l[2] + q3;
-    l[4] = l[0] + q1;
-    l[5] = l[4] + q3;
-    l[6] = l[4] + q2;
-    l[7] = l[6] + q3;
-    l[8] = l[0] + q0;
-    l[9] = l[8] + q3;
-    l[10] = l[8] + q2;
-    l[11] = l[10] + q3;
-    l[12] = l[8] + q1;
-    l[13] = l[12] + q3;
-    l[14] = l[12] + q2;
-    l[15] = l[14] + q3;
-}
-
-// k_prep for the FHT-Kac and identity rotators with ONE WAVE per query (4 queries per workgroup): no workgroup
-// barrier anywhere — the butterflies synchronise through the wave's in-order LDS traffic, the min/max and the
-// amin/amax sums are wave reductions, and the two strictly sequential sums (sum q, |q|^2: Rust iter().sum())
-// run side by side on lanes 0 and 1 of each wave.  Same arithmetic as k_prep, operation for operation.
-// dynamic LDS: 4 x 2 x D floats (vector + squares per wave) | 4*D/8 flip bytes
-__global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict__ queries, uint32_t nq, uint32_t dim, uint32_t D,
-                                                        uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
-                                                        uint32_t trunc, float fac, uint32_t ex_bits,
-                                                        float* __restrict__ rot_out, uint8_t* __restrict__ lut_out,
-                                                        QueryConsts* __restrict__ consts,
-                                                        uint16_t* __restrict__ rot_hi, uint16_t* __restrict__ rot_lo) {
-    extern __shared__ __align__(16) float sm[];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t q = blockIdx.x * (kThreads / 64) + wave;
-    uint8_t* flips = reinterpret_cast<uint8_t*>(sm + (size_t)2 * (kThreads / 64) * D); // 4*D/8 bytes (FHT-Kac)
-    if (rotator == 1) {
-        for (uint32_t i = threadIdx.x; i < D / 2; i += kThreads) flips[i] = rot_blob[i];
-        __syncthreads(); // the only workgroup barrier: before any wave can leave
-    }
-    if (q >= nq) return; // whole wave
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
-#endif
-    float* x = sm + (size_t)wave * 2 * D;
-    float* x2 = x + D; // squares, for the |q|^2 chain
-    const float* qin = queries + (size_t)q * dim;
-    if (rotator == 1) {
-        switch (trunc) {
-            case 64: rotate_fhtkac_wave<1>(x, qin, dim, D, flips, fac, lane); break;
-            case 128: rotate_fhtkac_wave<2>(x, qin, dim, D, flips, fac, lane); break;
-            case 256: rotate_fhtkac_wave<4>(x, qin, dim, D, flips, fac, lane); break;
-            case 512: rotate_fhtkac_wave<8>(x, qin, dim, D, flips, fac, lane); break;
-            case 1024: rotate_fhtkac_wave<16>(x, qin, dim, D, flips, fac, lane); break;
-            case 2048: rotate_fhtkac_wave<32>(x, qin, dim, D, flips, fac, lane); break;
-            // dim < 64 (transform shorter than a wavefront) or >= 4096: the generic LDS butterflies
-            default: rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, flips, trunc, fac, lane); break;
-        }
-    } else {
-        rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, rot_blob, trunc, fac, lane);
-    }
-
-    for (uint32_t i = lane; i < D; i += 64) {
-        const float v = x[i];
-        x2[i] = v * v;
-        rot_out[(size_t)q * D + i] = v;
-        if (rot_hi) { // split-bf16 image for k_rank_bf16_db
-            uint16_t h, l;
-            bf16_split(v, h, l);
-            rot_hi[(size_t)q * D + i] = h;
-            rot_lo[(size_t)q * D + i] = l;
-        }
-    }
-    group_sync<64>();
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
-#endif
-    // QueryPrecomputed::new — strictly sequential sums (Rust iter().sum() folds from -0.0): lane 0 adds the
-    // elements, lane 1 their squares
-    float acc = -0.0f;
-    if (lane < 2) { // 16 elements per step: four 16-byte LDS reads in flight, then the adds in element order
-        const float* src = lane ? x2 : x;
-        for (uint32_t i = 0; i < D; i += 16) { // D % 16 == 0
-            float4 v4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v4[u] = *reinterpret_cast<const float4*>(src + i + 4 * u);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = acc + v4[u].x;
-                acc = acc + v4[u].y;
-                acc = acc + v4[u].z;
-                acc = acc + v4[u].w;
-            }
-        }
-    }
-    const float s_sum = __shfl(acc, 0, 64), s_n2 = __shfl(acc, 1, 64);
-
-#ifdef RBQ_PREP_STAMPS
-    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
-#endif
-    // pack_lut_f32 + QueryLut::new: pass 1 finds the value range, pass 2 quantises
-    const uint32_t ncb = D / 4;
-    int kmin = 0x7fffffff, kmax = (int)0x80000000;
-    for (uint32_t c = lane; c < ncb; c += 64) {
-        float l[16];
-        lut_entries(x + 4 * c, l);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = total_key(l[j]);
-            kmin = k < kmin ? k : kmin;
-            kmax = k > kmax ? k : kmax;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const int a = __shfl_xor(kmin, d, 64), b = __shfl_xor(kmax, d, 64);
-        kmin = a < kmin ? a : kmin;
-        kmax = b > kmax ? b : kmax;
-    }
-    const float vl = key_to_float(kmin), vr = key_to_float(kmax);
-    const float delta = (vr - vl) / 255.0f;
-    uint32_t amin = 0, amax = 0;
-    for (uint32_t c = lane; c < Dc / 4; c += 64) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (c < ncb) {
-            float l[16];
-            lut_entries(x + 4 * c, l);
-            uint32_t emin = 255, emax = 0;
-            if (delta > 0.0f) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float v = roundf((l[j] - vl) / delta);
-                    v = v >= 0.0f ? v : 0.0f; // also maps NaN -> 0 like `as u8`
-                    v = v > 255.0f ? 255.0f : v;
-                    const uint32_t e = (uint32_t)v;
-                    emin = e < emin ? e : emin;
-                    emax = e > emax ? e : emax;
-                    w[j >> 2] |= e << (8 * (j & 3));
-                }
-            } else {
-                emin = 0;
-            }
-            amin += emin;
-            amax += emax;
-        }
-        // device LUT order: adjacent codebooks swapped (position p holds codebook p^1) so that nibble m of a
-        // little-endian code dword indexes table (8*dword + m) directly; padding codebooks are all-zero tables
-        *reinterpret_cast<uint4*>(lut_out + (size_t)q * Dc * 4 + (size_t)(c ^ 1u) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        amin += __shfl_xor(amin, d, 64);
-        amax += __shfl_xor(amax, d, 64);
-    }
-    if (lane == 0) {
-        QueryConsts qc;
-        qc.amin = (float)amin;
-        qc.amax = (float)amax;
-        qc.delta = delta;
-        qc.sum_vl = vl * (float)(D / 4);
-        qc.qnorm = sqrtf(s_n2);
-        qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
-#ifdef RBQ_PREP_STAMPS
-        qc.pad0 = (float)(pt1 - pt0); qc.pad1 = (float)(pt2 - pt1); qc.pad2 = (float)(__builtin_amdgcn_s_memtime() - pt2);
-#endif
-        qc.k1x = -0.5f * s_sum;
-        const float cb = -((float)(1u << ex_bits) - 0.5f);
-        qc.kbx = cb * s_sum;
-        qc.scale = (float)(1u << ex_bits);
-        consts[q] = qc;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_rank_scores: scores[q][c] = l2_distance_sqr(rot[q], cent[c]) or dot(...), in the reference's
-// AVX2 lane order: 8 strided accumulators, unfused mul/add, lanes summed 0..7, scalar tail.
-// Tile 32 queries x 32 centroids per workgroup, 2x2 pairs per thread, 32-dim LDS chunks.
-// ---------------------------------------------------------------------------------------------
-template <int METRIC>
-__global__ __launch_bounds__(kThreads) void k_rank_scores(const float* __restrict__ rot, const float* __restrict__ cent,
-                                                          uint32_t nq, uint32_t nlist, uint32_t D,
-                                                          float* __restrict__ scores) {
-    __shared__ __align__(16) float Qs[32][36];
-    __shared__ __align__(16) float Cs[32][36];
-    const uint32_t tid = threadIdx.x, tq = tid >> 4, tc = tid & 15;
-    const uint32_t q0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    const uint32_t Dmain = D & ~7u;
-    float acc[2][2][8];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) acc[a][b][l] = 0.0f;
-
-    const uint32_t lrow = tid >> 3, lcol = (tid & 7) * 4;
-    for (uint32_t k0 = 0; k0 < Dmain; k0 += 32) {
-        float4 qv = make_float4(0, 0, 0, 0), cv = make_float4(0, 0, 0, 0);
-        const uint32_t k = k0 + lcol;
-        if (q0 + lrow < nq) {
-            const float* p = rot + (size_t)(q0 + lrow) * D + k;
-            if (k + 4 <= Dmain && (D & 3) == 0) qv = *reinterpret_cast<const float4*>(p);
-            else {
-                if (k < Dmain) qv.x = p[0];
-                if (k + 1 < Dmain) qv.y = p[1];
-                if (k + 2 < Dmain) qv.z = p[2];
-                if (k + 3 < Dmain) qv.w = p[3];
-            }
-        }
-        if (c0 + lrow < nlist) {
-            const float* p = cent + (size_t)(c0 + lrow) * D + k;
-            if (k + 4 <= Dmain && (D & 3) == 0) cv = *reinterpret_cast<const float4*>(p);
-            else {
-                if (k < Dmain) cv.x = p[0];
-                if (k + 1 < Dmain) cv.y = p[1];
-                if (k + 2 < Dmain) cv.z = p[2];
-                if (k + 3 < Dmain) cv.w = p[3];
-            }
-        }
-        *reinterpret_cast<float4*>(&Qs[lrow][lcol]) = qv;
-        *reinterpret_cast<float4*>(&Cs[lrow][lcol]) = cv;
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float qa[2][8], cb[2][8];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                float4 v0 = *reinterpret_cast<const float4*>(&Qs[2 * tq + a][8 * t]);
-                float4 v1 = *reinterpret_cast<const float4*>(&Qs[2 * tq + a][8 * t + 4]);
-                qa[a][0] = v0.x; qa[a][1] = v0.y; qa[a][2] = v0.z; qa[a][3] = v0.w;
-                qa[a][4] = v1.x; qa[a][5] = v1.y; qa[a][6] = v1.z; qa[a][7] = v1.w;
-                float4 w0 = *reinterpret_cast<const float4*>(&Cs[2 * tc + a][8 * t]);
-                float4 w1 = *reinterpret_cast<const float4*>(&Cs[2 * tc + a][8 * t + 4]);
-                cb[a][0] = w0.x; cb[a][1] = w0.y; cb[a][2] = w0.z; cb[a][3] = w0.w;
-                cb[a][4] = w1.x; cb[a][5] = w1.y; cb[a][6] = w1.z; cb[a][7] = w1.w;
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int l = 0; l < 8; ++l) {
-                        float p;
-                        if (METRIC == 0) {
-                            float d = qa[a][l] - cb[b][l];
-                            p = d * d;
-                        } else {
-                            p = qa[a][l] * cb[b][l];
-                        }
-                        acc[a][b][l] = acc[a][b][l] + p;
-                    }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint32_t qi = q0 + 2 * tq + a, ci = c0 + 2 * tc + b;
-            if (qi < nq && ci < nlist) {
-                float sum = 0.0f;
-                if (Dmain > 0) {
-                    sum = -0.0f;
-#pragma unroll
-                    for (int l = 0; l < 8; ++l) sum = sum + acc[a][b][l];
-                }
-                for (uint32_t i = Dmain; i < D; ++i) { // scalar tail
-                    float x = rot[(size_t)qi * D + i], y = cent[(size_t)ci * D + i], p;
-                    if (METRIC == 0) {
-                        float d = x - y;
-                        p = d * d;
-                    } else {
-                        p = x * y;
-                    }
-                    sum = sum + p;
-                }
-                scores[(size_t)qi * nlist + ci] = sum;
-            }
-        }
-}
-
 // canonical single-pair reductions used for the second per-probe quantity
 __device__ inline float canon_l2(const float* a, const float* __restrict__ b, uint32_t D) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -772,136 +220,6 @@ __device__ __forceinline__ uint64_t make_key(float score, uint32_t cid, int metr
     int32_t k = total_key(score);
     if (metric == 1) k = ~k; // descending score
     return ((uint64_t)((uint32_t)k ^ 0x80000000u) << 32) | cid;
-}
-
-__global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ scores, uint32_t nlist, uint32_t nprobe,
-                                                     uint32_t np2, int metric, const float* __restrict__ rot,
-                                                     const float* __restrict__ cent, uint32_t D,
-                                                     const uint32_t* __restrict__ list_gb0,
-                                                     const uint32_t* __restrict__ list_n,
-                                                     ProbeInfo* __restrict__ probe, StreamItem* __restrict__ wl,
-                                                     uint64_t wl_stride, uint32_t* __restrict__ nstream,
-                                                     unsigned long long* __restrict__ nvec_probed,
-                                                     unsigned long long* __restrict__ prof_total,
-                                                     const QueryConsts* __restrict__ consts,
-                                                     const BlockSummary* __restrict__ bsum) {
-    extern __shared__ __align__(16) unsigned char smraw[];
-    uint64_t* sel = reinterpret_cast<uint64_t*>(smraw);
-    float* qrot = reinterpret_cast<float*>(smraw + (size_t)np2 * 8);
-    uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
-    __shared__ uint32_t hist[256];
-    __shared__ uint64_t s_prefix, s_mask;
-    __shared__ uint32_t s_k, s_cnt;
-    __shared__ unsigned long long s_nvec;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const float* sc = scores + (size_t)q * nlist;
-
-    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
-    if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; }
-    __syncthreads();
-
-    if (nprobe < nlist) {
-        for (int pass = 7; pass >= 0; --pass) {
-            const int shift = pass * 8;
-            hist[tid] = 0;
-            __syncthreads();
-            const uint64_t prefix = s_prefix, mask = s_mask;
-            for (uint32_t i = tid; i < nlist; i += kThreads) {
-                uint64_t key = make_key(sc[i], i, metric);
-                if ((key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t k = s_k, cum = 0, b = 0;
-                for (; b < 256; ++b) {
-                    uint32_t h = hist[b];
-                    if (k < cum + h) break;
-                    cum += h;
-                }
-                s_k = k - cum;
-                s_prefix = prefix | ((uint64_t)b << shift);
-                s_mask = mask | (0xffull << shift);
-            }
-            __syncthreads();
-        }
-    } else if (tid == 0) {
-        s_prefix = ~0ull;
-    }
-    __syncthreads();
-    const uint64_t kstar = s_prefix;
-    for (uint32_t i = tid; i < np2; i += kThreads) sel[i] = ~0ull;
-    __syncthreads();
-    for (uint32_t i = tid; i < nlist; i += kThreads) {
-        uint64_t key = make_key(sc[i], i, metric);
-        if (key <= kstar) {
-            uint32_t pos = atomicAdd(&s_cnt, 1u);
-            if (pos < np2) sel[pos] = key;
-        }
-    }
-    __syncthreads();
-    // bitonic sort ascending
-    for (uint32_t k = 2; k <= np2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < np2; i += kThreads) {
-                uint32_t ixj = i ^ j;
-                if (ixj > i) {
-                    uint64_t a = sel[i], b = sel[ixj];
-                    bool up = (i & k) == 0;
-                    if ((a > b) == up) { sel[i] = b; sel[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-
-    // per-probe constants (src/ivf.rs:1850-1857) + block counts
-    const uint32_t per = (nprobe + kThreads - 1) / kThreads;
-    const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
-    uint32_t local = 0;
-    unsigned long long local_vec = 0;
-    for (uint32_t r = r0; r < r1; ++r) {
-        uint32_t cid = (uint32_t)(sel[r] & 0xffffffffu);
-        float s = sc[cid], dist, dot;
-        const float* c = cent + (size_t)cid * D;
-        // L2: score IS the centroid distance; the dot product only feeds the non-finite lower-bound
-        // fallback of the IP metric (src/ivf.rs:2031-2042), so it is not computed here.
-        if (metric == 0) { dist = s; dot = 0.0f; }
-        else { dot = s; dist = canon_l2(qrot, c, D); }
-        ProbeInfo pi;
-        pi.g_add = metric == 0 ? dist : -dot;
-        pi.g_err = sqrtf(dist);
-        pi.dotqc = dot;
-        pi.cid = cid;
-        probe[(size_t)q * nprobe + r] = pi;
-        local += (list_n[cid] + 31u) >> 5;
-        local_vec += list_n[cid];
-    }
-    part[tid] = local;
-    if (local_vec) atomicAdd(&s_nvec, local_vec);
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < kThreads; ++i) { uint32_t v = part[i]; part[i] = run; run += v; }
-        nstream[q] = run;
-        nvec_probed[q] = s_nvec; // sum of n_c over the probed lists: the scan's algorithmic work
-        if (prof_total) atomicAdd(prof_total, s_nvec);
-    }
-    __syncthreads();
-    uint64_t pos = (uint64_t)q * wl_stride + part[tid];
-    const QueryConsts qc = consts[q];
-    for (uint32_t r = r0; r < r1; ++r) {
-        uint32_t cid = (uint32_t)(sel[r] & 0xffffffffu);
-        uint32_t n = list_n[cid], gb = list_gb0[cid], nb = (n + 31u) >> 5;
-        const ProbeInfo pi = probe[(size_t)q * nprobe + r]; // written by this thread above
-        for (uint32_t b = 0; b < nb; ++b) {
-            uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
-            StreamItem wi;
-            wi.gblock = gb + b;
-            wi.rank_nvalid = (r << 6) | nv;
-            wi.lbmin = block_lbmin(bsum[gb + b], pi.g_add, pi.g_err, qc);
-            wi.pad = 0;
-            wl[pos++] = wi;
-        }
-    }
 }
 
 } // namespace rbq

@@ -1,0 +1,136 @@
+// launch.hpp — host-callable launchers of the kernel translation units.  rbq_api.hip (pure host code) sees the
+// kernels only through these; each .hip file below compiles on its own, so a change to the host side does not
+// rebuild k_scan's instantiations and vice versa.
+//   k_query.hip  k_prep / k_prep_wave, k_rank_* , k_select*, k_probes_given     (kernels.hpp, rank_mfma.hpp)
+//   k_scan.hip   k_scan<DT, EX, TR>                                               (scan.hpp)
+//   k_build.hip  encoder, reference-layout -> device-layout converters, sorting   (encode.hpp)
+#pragma once
+#include "types.hpp"
+
+namespace rbq {
+
+// Raises a kernel's dynamic-LDS limit once per (kernel, device, size): hipFuncSetAttribute is slow and serialises
+// launches, so the largest value set so far is remembered per device.
+struct LdsAttrCache {
+    size_t set[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t ensure(const void* fn, size_t lds, int device);
+};
+
+struct PrepParams {
+    const float* queries; // [nq][dim]
+    uint32_t nq, dim, D, Dc;
+    int rotator;
+    const uint8_t* rot_blob;
+    uint32_t trunc;
+    float fac;
+    uint32_t ex_bits;
+    float* rot;          // [nq][D]
+    uint8_t* lut;        // [nq][4Dc]
+    QueryConsts* consts; // [nq]
+    uint16_t *rot_hi, *rot_lo; // split-bf16 image or null
+    bool wg_prep;        // one workgroup per query (always for the matrix rotator)
+};
+hipError_t launch_prep(const PrepParams& p, int device, hipStream_t s);
+
+struct RankParams {
+    int metric;
+    const float* rot;
+    const uint16_t *rot_hi, *rot_lo;
+    const float* cent;
+    const uint16_t *cent_hi, *cent_lo;
+    const QueryConsts* consts;
+    const float* cnorm2;
+    uint32_t nq, nlist, D;
+    float* scores; // [nq][nlist]
+    bool split;    // split-bf16 MFMA GEMM (else f32 MFMA)
+    bool big;      // 128x128 tiles
+};
+hipError_t launch_rank_exact(const RankParams& p, hipStream_t s);
+hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s);
+
+struct SelectParams {
+    float* scores;
+    uint32_t nq, nlist, nprobe;
+    int metric;
+    const float* rot;
+    const float* cent;
+    uint32_t D;
+    const QueryConsts* consts;
+    float cnorm2_max;
+    const uint32_t *list_gb0, *list_n;
+    ProbeInfo* probe;
+    StreamItem* wl;
+    uint64_t wl_stride;
+    uint32_t* nstream;
+    unsigned long long* nvec;
+    unsigned long long* prof_total; // null unless a profile is open
+    unsigned int* fallback_count;
+    int force_fallback;
+    const BlockSummary* bsum;
+};
+hipError_t launch_select_exact(const SelectParams& p, hipStream_t s);
+hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s);
+
+struct ProbesGivenParams {
+    const uint32_t *list_ids, *list_counts;
+    uint32_t max_lists, nq, nlist;
+    int metric;
+    const float* rot;
+    const float* cent;
+    uint32_t D;
+    const uint32_t *list_gb0, *list_n;
+    ProbeInfo* probe;
+    StreamItem* wl;
+    uint64_t wl_stride;
+    uint32_t* nstream;
+    const QueryConsts* consts;
+    const BlockSummary* bsum;
+};
+hipError_t launch_probes_given(const ProbesGivenParams& p, hipStream_t s);
+
+// ev0/ev1: null, or an event pair carried by the dispatch packet itself (hipExtLaunchKernelGGL)
+hipError_t launch_scan(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+
+// ---- k_build.hip -------------------------------------------------------------------------------------------------
+hipError_t launch_rotate_rows(const float* src, const uint32_t* map, uint32_t nrows, uint32_t dim, uint32_t D, int rotator,
+                              const uint8_t* rot_blob, uint32_t trunc, float fac, float* rows, hipStream_t s);
+hipError_t launch_encode(const EncodeParams& P, hipStream_t s);
+// raw ex codes [row][D] u8 -> lane-major units of slot (row_slot ? row_slot[row] : row) in `ex`
+hipError_t launch_pack_ex(const uint8_t* raw, const uint32_t* slot_src, const uint32_t* row_slot, uint32_t nrows, uint32_t D,
+                          uint32_t ex_bits, uint8_t* ex, hipStream_t s);
+hipError_t launch_block_summary(const uint8_t* blocks, const uint32_t* block_nv, uint32_t nblocks, uint32_t Dc, BlockSummary* bsum,
+                                hipStream_t s);
+hipError_t launch_count_assign(const uint32_t* assign, uint64_t n, uint32_t nlist, uint32_t* counts, uint32_t* err, hipStream_t s);
+hipError_t launch_iota(uint32_t* x, uint64_t n, hipStream_t s);
+hipError_t launch_scatter_slots(const uint32_t* sorted_list, const uint32_t* sorted_src, uint64_t n, const uint32_t* list_gb0,
+                                const uint64_t* vstart, uint32_t* slot_src, hipStream_t s);
+// stable radix sort of (key, value) u32 pairs on the low `bits` bits; tmp == null returns the scratch size in *tmp_bytes
+hipError_t sort_pairs_u32(void* tmp, size_t* tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
+                          uint32_t* vals_out, size_t n, unsigned bits, hipStream_t s);
+// streamed build: rows of a pushed chunk sorted by (list, source index) -> first row per list, global slot per row
+// (first slot of the list + vectors pushed by earlier chunks + rank in this chunk), then advance the cursors
+hipError_t launch_chunk_first(const uint32_t* sorted_list, uint32_t n, uint32_t* chunk_first, hipStream_t s);
+hipError_t launch_chunk_slots(const uint32_t* sorted_list, const uint32_t* sorted_src, uint32_t n, const uint32_t* list_gb0,
+                              const uint32_t* list_cursor, const uint32_t* chunk_first, uint32_t* row_src, uint32_t* row_slot,
+                              hipStream_t s);
+hipError_t launch_chunk_advance(const uint32_t* sorted_list, uint32_t n, const uint32_t* chunk_first, uint32_t* list_cursor,
+                                hipStream_t s);
+// reference layout -> device layout (rbq_index_create / load_rbq1): `recs` = the reference's batch records of nb
+// blocks back to back; `exsrc` = the packed ex codes of the chunk's vectors, dense, in list order; block b's first
+// vector is entry block_dense0[b] of the dense arrays
+hipError_t launch_relayout_blocks(const uint8_t* recs, uint32_t nb, uint32_t D, uint32_t Dc, uint8_t* blocks, hipStream_t s);
+hipError_t launch_relayout_ex(const uint8_t* exsrc, const uint64_t* block_dense0, const uint32_t* block_nv,
+                              uint32_t nb, uint32_t D, uint32_t ex_bits, uint8_t* ex, hipStream_t s);
+// per-slot arrays from per-vector (dense, list order) arrays: dst[b*32+v] = v < nv[b] ? src[dense0[b]+v] : fill
+hipError_t launch_spread_u64(const uint64_t* src, const uint64_t* block_dense0, const uint32_t* block_nv, uint32_t nb, uint64_t fill,
+                             uint64_t* dst, hipStream_t s);
+hipError_t launch_spread_f32(const float* src, const uint64_t* block_dense0, const uint32_t* block_nv, uint32_t nb, float fill,
+                             float* dst, hipStream_t s);
+// centroid-derived arrays: squared norms (f64 accumulate, as the host did) and the split-bf16 image
+hipError_t launch_centroid_arrays(const float* cent, uint32_t nlist, uint32_t D, float* cnorm2, uint16_t* hi, uint16_t* lo,
+                                  hipStream_t s);
+// exact re-scoring of the returned ids against caller-supplied raw vectors (optional rerank, default off)
+hipError_t launch_rerank(const float* queries, uint32_t nq, uint32_t dim, const float* raw, uint64_t n_raw, int metric,
+                         uint32_t top_k, uint64_t* ids, float* scores, const uint32_t* counts, hipStream_t s);
+
+} // namespace rbq

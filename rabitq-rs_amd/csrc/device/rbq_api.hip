@@ -1,28 +1,28 @@
-// rbq_api.hip — C ABI (include/rbq.h) over the HIP kernels of kernels.hpp.  gfx950 only.
+// rbq_api.hip — C ABI (include/rbq.h) over the HIP kernels.  Host code only: the kernels live in k_query.hip,
+// k_scan.hip and k_build.hip and are reached through launch.hpp.  gfx950 only.
 //
-// Host responsibilities: validate like the reference (src/ivf.rs:1754-1769,1484-1702), re-lay the
-// reference's ClusterData bytes into the device layout (one-time, at create/load), own HBM, and
-// enqueue prep -> rank -> select -> scan for each query batch.  There is no CPU compute path:
-// every failure to reach the GPU surfaces as RBQ_DEVICE.
+// Host responsibilities: validate like the reference (src/ivf.rs:1754-1769,1484-1702), upload the reference's
+// ClusterData bytes and have the GPU re-lay them into the device layout (one-time, at create/load), own HBM on one
+// or N devices (replicas), and enqueue prep -> rank -> select -> scan for each query batch.  There is no CPU
+// compute path: every failure to reach the GPU surfaces as RBQ_DEVICE.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rbq.h"
-#include "kernels.hpp"
-#include "scan.hpp"
-#include "rank_mfma.hpp"
-#include "encode.hpp"
-#include <rocprim/rocprim.hpp>
+#include "launch.hpp"
 
 using namespace rbq;
 
@@ -42,8 +42,30 @@ int fail(int code, const std::string& detail) {
             return fail(RBQ_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));             \
     } while (0)
 
+// No C++ exception may cross the C boundary (the Rust host is panic = "abort", Cargo.toml:59; ctypes would
+// terminate): every entry point runs inside this guard.
+#define RBQ_GUARD_BEGIN try {
+#define RBQ_GUARD_END                                                                               \
+    } catch (const std::bad_alloc&) { return fail(RBQ_IO, "out of host memory"); }                 \
+    catch (const std::exception& e) { return fail(RBQ_IO, std::string("internal error: ") + e.what()); } \
+    catch (...) { return fail(RBQ_IO, "internal error"); }
+
+// Entry points switch to the index's device and put the caller's device back on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 uint32_t floor_log2_u32(uint32_t x) { uint32_t r = 0; while (x >>= 1) ++r; return r; }
-uint32_t next_pow2(uint32_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct DevBuf {
     void* p = nullptr;
@@ -59,16 +81,33 @@ struct DevBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+struct PinBuf { // page-locked host staging
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return RBQ_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return RBQ_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_ids, out_scores, out_counts, diag, filter, rot_hi, rot_lo;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo;
+    PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
+    hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     void release() {
-        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_ids, &out_scores,
-                          &out_counts, &diag, &filter})
+        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter})
             b->release();
+        h_in.release(); h_out.release();
+        if (done) (void)hipEventDestroy(done);
         if (stream) (void)hipStreamDestroy(stream);
-        stream = nullptr;
+        stream = nullptr; done = nullptr;
     }
 };
 
@@ -96,26 +135,28 @@ struct EventPool {
     }
 };
 
-} // namespace
+struct Arr { // one device array of a replica (size kept for cloning)
+    void* p = nullptr;
+    size_t bytes = 0;
+};
 
-struct rbq_index {
+// One device-resident copy of the index.
+struct Replica {
     int device = 0;
     uint32_t dim = 0, D = 0, Dc = 0;
     uint8_t metric = 0, rotator = 0, ex_bits = 0;
     uint64_t n_vectors = 0, n_lists = 0, n_blocks = 0;
     uint32_t trunc = 0;
     float fac = 1.0f;
-    // device arrays
-    void *d_rot_blob = nullptr, *d_centroids = nullptr, *d_blocks = nullptr, *d_ids = nullptr, *d_ex = nullptr,
-         *d_fadd_ex = nullptr, *d_fres_ex = nullptr, *d_list_gb0 = nullptr, *d_list_n = nullptr, *d_prof_total = nullptr, *d_bsum = nullptr, *d_cnorm2 = nullptr, *d_fallbacks = nullptr, *d_cent_hi = nullptr, *d_cent_lo = nullptr;
+    Arr rot_blob, centroids, blocks, ids, ex, fadd_ex, fres_ex, list_gb0, list_n, prof, bsum, cnorm2, fallbacks, cent_hi, cent_lo, raw;
+    Arr* arrays[16] = {&rot_blob, &centroids, &blocks, &ids, &ex, &fadd_ex, &fres_ex, &list_gb0, &list_n, &prof, &bsum, &cnorm2,
+                       &fallbacks, &cent_hi, &cent_lo, &raw};
     float cnorm2_max = 0.0f;
-    bool no_block_bound = false; // rbq_debug_set_option("block_bound", 0)
-    bool f32_rank = false;       // rbq_debug_set_option("f32_rank", 1): f32 MFMA GEMM instead of the split-bf16 one
-    bool small_rank_tiles = false; // rbq_debug_set_option("small_rank_tiles", 1): 64x64 GEMM tiles whatever the problem size
-    bool wg_prep = false;        // rbq_debug_set_option("wg_prep", 1): workgroup-per-query k_prep for every rotator
-    bool exact_heap = false;     // rbq_debug_set_option("exact_heap", 1): BinaryHeap emulation from the first candidate
-    bool force_rank_fallback = false; // RBQ_FORCE_RANK_FALLBACK=1: exercise the all-lists canonical fallback
-    bool exact_rank = false; // RBQ_EXACT_RANK=1: rank all pairs in canonical order (A/B and debugging)
+    uint64_t n_raw = 0;      // raw vectors attached for the optional rerank
+    bool raw_borrowed = false;
+    bool rerank = false;
+    bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
+         force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     // host
     std::vector<uint32_t> h_list_n;
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
@@ -127,82 +168,51 @@ struct rbq_index {
     uint32_t prof_mask = 0xf; // stages that are timed while `profiling` (bit s = stage s)
     uint32_t prof_every = 1;  // time every n-th launch of a stage
     uint32_t prof_seq[4] = {0, 0, 0, 0};
-    StageProf prof[4]; // prep, rank, select, scan
+    StageProf stage_prof[4]; // prep, rank, select, scan
     EventPool ev_pool;
-    uint64_t prof_scan_bytes = 0;
+    uint64_t prof_counters[kProfSlots] = {0, 0, 0, 0, 0, 0, 0, 0};
+    Replica() = default;
+    Replica(const Replica&) = delete;
+};
+
+} // namespace
+
+struct rbq_index {
+    std::vector<Replica*> reps; // reps[r] lives on device reps[r]->device; all hold the same index
+    int debug_replica = 0;      // which replica the rbq_debug_copy_* calls read
 };
 
 namespace {
 
-void free_index(rbq_index* ix) {
+int alloc_arr(Arr& a, size_t bytes) {
+    HIP_TRY(hipMalloc(&a.p, bytes ? bytes : 16));
+    a.bytes = bytes;
+    return RBQ_OK;
+}
+int upload_arr(Arr& a, const void* src, size_t bytes) {
+    int rc = alloc_arr(a, bytes);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpy(a.p, src, bytes, hipMemcpyHostToDevice));
+    return RBQ_OK;
+}
+
+void free_replica(Replica* ix) {
     if (!ix) return;
-    (void)hipSetDevice(ix->device);
-    for (void* p : {ix->d_rot_blob, ix->d_centroids, ix->d_blocks, ix->d_ids, ix->d_ex, ix->d_fadd_ex, ix->d_fres_ex,
-                    ix->d_list_gb0, ix->d_list_n, ix->d_prof_total, ix->d_bsum, ix->d_cnorm2, ix->d_fallbacks, ix->d_cent_hi, ix->d_cent_lo})
-        if (p) (void)hipFree(p);
+    DeviceGuard g(ix->device);
+    (void)hipDeviceSynchronize();
+    for (Arr* a : ix->arrays)
+        if (a->p && !(a == &ix->raw && ix->raw_borrowed)) (void)hipFree(a->p);
     for (Workspace* w : ix->pool) { w->release(); delete w; }
     for (auto& kv : ix->stream_ws) { kv.second->release(); delete kv.second; }
-    for (auto& sp : ix->prof)
+    for (auto& sp : ix->stage_prof)
         for (auto& e : sp.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     ix->ev_pool.destroy();
     delete ix;
 }
-
-// inverse of pack_codes (src/simd.rs:864-904): KPERM0[j] = (j>>1) + 8*(j&1)  =>  j = 2*(u&7) + (u>>3)
-inline uint8_t fastscan_byte(const uint8_t* packed, size_t col, uint32_t v) {
-    const uint32_t u = v & 15u, j = 2u * (u & 7u) + (u >> 3);
-    const uint8_t a = packed[col * 32 + j], b = packed[col * 32 + 16 + j];
-    const uint8_t hi = v < 16 ? (a & 15) : (a >> 4);
-    const uint8_t lo = v < 16 ? (b & 15) : (b >> 4);
-    return (uint8_t)((hi << 4) | lo);
-}
-
-// Reference packed ex code of one vector (src/simd.rs:2478-2541,2601-2695) -> device lane-major record:
-// lane l = dim % 16 holds codes of dims 16t+l as a little-endian bit string (ex bits each), stored
-// [j][lane][16 B] so that 16 lanes read 256 contiguous bytes per 16-byte load.
-void relayout_ex(const uint8_t* src, uint32_t D, uint32_t ex_bits, uint8_t* dst) {
-    const uint32_t w4 = ex_w4(D, ex_bits);
-    std::memset(dst, 0, (size_t)w4 * 256);
-    uint32_t* out = reinterpret_cast<uint32_t*>(dst);
-    for (uint32_t t = 0; t < D / 16; ++t) {
-        uint32_t codes[16];
-        if (ex_bits == 2) {
-            uint32_t w;
-            std::memcpy(&w, src + t * 4, 4);
-            for (uint32_t l = 0; l < 16; ++l) codes[l] = (w >> (8 * (l & 3) + 2 * (l >> 2))) & 3u;
-        } else { // 6
-            uint64_t lo;
-            uint32_t hi;
-            std::memcpy(&lo, src + t * 12, 8);
-            std::memcpy(&hi, src + t * 12 + 8, 4);
-            for (uint32_t l = 0; l < 16; ++l) {
-                const uint32_t low4 = l < 8 ? (uint32_t)((lo >> (8 * l)) & 15u) : (uint32_t)((lo >> (8 * (l - 8) + 4)) & 15u);
-                const uint32_t top2 = (hi >> (8 * (l & 3) + 2 * (l >> 2))) & 3u;
-                codes[l] = low4 | (top2 << 4);
-            }
-        }
-        const uint32_t cpu = ex_cpu(ex_bits), unit = t / cpu, k = t % cpu;
-        const uint32_t bit = k * ex_bits, idx = bit >> 5, sh = bit & 31u; // inside the 128-bit unit
-        for (uint32_t l = 0; l < 16; ++l) {
-            uint32_t* u = out + (unit * 16 + l) * 4;
-            u[idx] |= codes[l] << sh;
-            if (sh + ex_bits > 32) u[idx + 1] |= codes[l] >> (32 - sh);
-        }
-    }
-}
-
-// One reference batch record -> one device block: lane-major code granules + the three factor rows.
-void relayout_block(const uint8_t* rec, uint32_t D, uint32_t Dc, uint8_t* dst) {
-    const size_t dim_bytes = D / 8, G16 = Dc >> 7;
-    std::memset(dst, 0, (size_t)Dc * 4);
-    for (uint32_t v = 0; v < 32; ++v)
-        for (size_t col = 0; col < dim_bytes; ++col) {
-            const uint8_t b = fastscan_byte(rec, col, v);
-            const size_t g = col >> 4;
-            if (g < G16) dst[g * 512 + v * 16 + (col & 15)] = b;
-            else dst[G16 * 512 + v * 8 + (col & 7)] = b;
-        }
-    std::memcpy(dst + (size_t)Dc * 4, rec + (size_t)D * 4, 384);
+void free_index(rbq_index* h) {
+    if (!h) return;
+    for (Replica* r : h->reps) free_replica(r);
+    delete h;
 }
 
 int validate_header(const rbq_header* h) {
@@ -216,6 +226,7 @@ int validate_header(const rbq_header* h) {
     if (h->padded_dim % 16 != 0) return fail(RBQ_INVALID_CONFIG, "Dimension must be multiple of 16 for SIMD");
     if (h->padded_dim > 2048)
         return fail(RBQ_INVALID_CONFIG, "padded_dim > 2048 (high-accuracy i32 LUT mode) is not supported");
+    if (h->rotator_len != 0 && !h->rotator_blob) return fail(RBQ_INVALID_CONFIG, "null rotator blob");
     if (h->rotator == RBQ_ROTATOR_NONE) {
         if (h->padded_dim != h->dim) return fail(RBQ_INVALID_CONFIG, "rotator NONE requires padded_dim == dim");
         if (h->rotator_len != 0) return fail(RBQ_INVALID_CONFIG, "rotator NONE takes no rotator blob");
@@ -230,40 +241,239 @@ int validate_header(const rbq_header* h) {
     return RBQ_OK;
 }
 
-template <typename T>
-int upload(void** dptr, const std::vector<T>& v) {
-    size_t bytes = v.size() * sizeof(T);
-    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
-    if (bytes) HIP_TRY(hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice));
+// device list: n_devices ordinals, or the current device
+int resolve_devices(int n_devices, const int* devices, std::vector<int>& out) {
+    if (n_devices < 1 || n_devices > 16) return fail(RBQ_INVALID_CONFIG, "n_devices must be in 1..16");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    out.clear();
+    for (int i = 0; i < n_devices; ++i) {
+        int d = 0;
+        if (devices) d = devices[i];
+        else if (n_devices == 1) HIP_TRY(hipGetDevice(&d));
+        else d = i;
+        if (d < 0 || d >= count) return fail(RBQ_INVALID_CONFIG, "no such device: " + std::to_string(d));
+        out.push_back(d);
+    }
     return RBQ_OK;
 }
 
-// arrays derived from the rotated centroids + the diagnostic counters (shared by create_impl and the device build)
-int finish_centroid_arrays(rbq_index* ix, const std::vector<float>& cent) {
-    const uint32_t D = ix->D;
-    std::vector<float> cn(ix->n_lists);
-    double mx = 0;
-    for (uint64_t c = 0; c < ix->n_lists; ++c) {
-        double a = 0;
-        for (uint32_t i = 0; i < D; ++i) a += (double)cent[c * D + i] * (double)cent[c * D + i];
-        cn[c] = (float)a;
-        if (std::isfinite(a)) mx = std::max(mx, a);
+Replica* new_replica(const rbq_header* hdr, int dev) {
+    Replica* ix = new Replica();
+    ix->device = dev;
+    ix->dim = hdr->dim; ix->D = hdr->padded_dim; ix->Dc = (hdr->padded_dim + 63u) / 64u * 64u;
+    ix->metric = hdr->metric; ix->rotator = hdr->rotator; ix->ex_bits = hdr->ex_bits;
+    ix->n_lists = hdr->n_lists;
+    ix->trunc = 1u << floor_log2_u32(hdr->dim);
+    ix->fac = 1.0f / std::sqrt((float)ix->trunc);
+    return ix;
+}
+
+// what every construction path shares once list sizes and rotated centroids are on the device: block geometry on
+// the host side, centroid-derived arrays, counters, environment switches
+int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
+    const uint32_t nlist = (uint32_t)ix->n_lists, D = ix->D;
+    ix->h_list_n = ln;
+    {
+        std::vector<uint64_t> nblk(nlist);
+        for (uint32_t c = 0; c < nlist; ++c) nblk[c] = (ln[c] + 31u) / 32u;
+        std::sort(nblk.begin(), nblk.end(), std::greater<uint64_t>());
+        ix->nblk_desc_prefix.assign((size_t)nlist + 1, 0);
+        for (uint32_t c = 0; c < nlist; ++c) ix->nblk_desc_prefix[c + 1] = ix->nblk_desc_prefix[c] + nblk[c];
     }
-    ix->cnorm2_max = (float)(mx * 1.0000002); // rounded up
     int rc;
-    if ((rc = upload(&ix->d_cnorm2, cn))) return rc;
-    std::vector<uint16_t> ch(cent.size()), cl(cent.size()); // split-bf16 image of the centroids (k_rank_bf16_db)
-    for (size_t i = 0; i < cent.size(); ++i) bf16_split(cent[i], ch[i], cl[i]);
-    if ((rc = upload(&ix->d_cent_hi, ch))) return rc;
-    if ((rc = upload(&ix->d_cent_lo, cl))) return rc;
-    std::vector<unsigned int> z(2, 0); // [0] rank fallbacks, [1] heap restarts
-    if ((rc = upload(&ix->d_fallbacks, z))) return rc;
-    std::vector<unsigned long long> z1(1, 0);
-    if ((rc = upload(&ix->d_prof_total, z1))) return rc;
+    if ((rc = alloc_arr(ix->cnorm2, (size_t)nlist * 4))) return rc;
+    if ((rc = alloc_arr(ix->cent_hi, (size_t)nlist * D * 2))) return rc;
+    if ((rc = alloc_arr(ix->cent_lo, (size_t)nlist * D * 2))) return rc;
+    HIP_TRY(launch_centroid_arrays((const float*)ix->centroids.p, nlist, D, (float*)ix->cnorm2.p, (uint16_t*)ix->cent_hi.p,
+                                   (uint16_t*)ix->cent_lo.p, 0));
+    std::vector<float> cn(nlist);
+    HIP_TRY(hipMemcpy(cn.data(), ix->cnorm2.p, (size_t)nlist * 4, hipMemcpyDeviceToHost));
+    double mx = 0;
+    for (float v : cn) if (std::isfinite(v)) mx = std::max(mx, (double)v);
+    ix->cnorm2_max = (float)(mx * 1.000001); // rounded up
+    if ((rc = alloc_arr(ix->fallbacks, 8))) return rc;   // [0] rank fallbacks, [1] heap restarts
+    HIP_TRY(hipMemset(ix->fallbacks.p, 0, 8));
+    if ((rc = alloc_arr(ix->prof, kProfSlots * 8))) return rc;
+    HIP_TRY(hipMemset(ix->prof.p, 0, kProfSlots * 8));
     const char* e = std::getenv("RBQ_EXACT_RANK");
     ix->exact_rank = e && e[0] == '1';
     const char* f = std::getenv("RBQ_FORCE_RANK_FALLBACK");
     ix->force_rank_fallback = f && f[0] == '1';
+    return RBQ_OK;
+}
+
+// A second replica of `src` on device `dev` (may be the same device: exercised by tests on one GPU).
+int clone_replica(const Replica* src, int dev, Replica** out) {
+    DeviceGuard g(dev);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    Replica* ix = new Replica();
+    ix->device = dev;
+    ix->dim = src->dim; ix->D = src->D; ix->Dc = src->Dc; ix->metric = src->metric; ix->rotator = src->rotator; ix->ex_bits = src->ex_bits;
+    ix->n_vectors = src->n_vectors; ix->n_lists = src->n_lists; ix->n_blocks = src->n_blocks; ix->trunc = src->trunc; ix->fac = src->fac;
+    ix->cnorm2_max = src->cnorm2_max; ix->h_list_n = src->h_list_n; ix->nblk_desc_prefix = src->nblk_desc_prefix;
+    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback;
+    for (size_t i = 0; i < sizeof(ix->arrays) / sizeof(ix->arrays[0]); ++i) {
+        const Arr* s = src->arrays[i];
+        Arr* d = ix->arrays[i];
+        if (!s->p || s == &src->raw) continue;
+        hipError_t e = hipMalloc(&d->p, s->bytes ? s->bytes : 16);
+        if (e == hipSuccess && s->bytes) {
+            if (dev == src->device) e = hipMemcpy(d->p, s->p, s->bytes, hipMemcpyDeviceToDevice);
+            else e = hipMemcpyPeer(d->p, dev, s->p, src->device, s->bytes); // xGMI peer copy (staged through the host if no peer access)
+        }
+        if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, std::string("replicating the index: ") + hipGetErrorString(e)); }
+        d->bytes = s->bytes;
+    }
+    hipError_t e = hipMemset(ix->fallbacks.p, 0, 8);
+    if (e == hipSuccess) e = hipMemset(ix->prof.p, 0, kProfSlots * 8);
+    if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, hipGetErrorString(e)); }
+    *out = ix;
+    return RBQ_OK;
+}
+
+int wrap_and_replicate(Replica* first, const std::vector<int>& devs, rbq_index** out) {
+    rbq_index* h = new rbq_index();
+    h->reps.push_back(first);
+    for (size_t i = 1; i < devs.size(); ++i) {
+        Replica* r = nullptr;
+        int rc = clone_replica(first, devs[i], &r);
+        if (rc) { free_index(h); return rc; }
+        h->reps.push_back(r);
+    }
+    *out = h;
+    return RBQ_OK;
+}
+
+// ---- create / load: reference layout in, device layout out --------------------------------------------------------
+// One ClusterData as byte ranges (an RBQ1 stream has no alignment; rbq_list_view arrays are viewed the same way).
+struct ListSrc {
+    const uint8_t* centroid = nullptr; // D f32
+    uint64_t n = 0;
+    const uint8_t* ids = nullptr;        // n u64
+    const uint8_t* batch_data = nullptr; // ceil(n/32) records of D*4 + 384 bytes
+    const uint8_t* ex = nullptr;         // n packed ex codes, `ex_stride` bytes apart
+    size_t ex_stride = 0;
+    const uint8_t* fadd = nullptr;       // n f32
+    const uint8_t* fres = nullptr;       // n f32
+};
+
+int create_from_sources(const rbq_header* hdr, const std::vector<ListSrc>& lists, int dev, Replica** out) {
+    DeviceGuard g(dev);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    Replica* ix = new_replica(hdr, dev);
+    struct Cleanup { Replica*& ix; std::vector<void*> dev_tmp; std::vector<void*> pin_tmp; std::vector<hipEvent_t> evs; hipStream_t st = nullptr;
+        ~Cleanup() { for (void* p : dev_tmp) (void)hipFree(p); for (void* p : pin_tmp) (void)hipHostFree(p);
+                     for (hipEvent_t e : evs) (void)hipEventDestroy(e); if (st) (void)hipStreamDestroy(st); if (ix) free_replica(ix); } } cl{ix};
+    const uint32_t D = ix->D, Dc = ix->Dc, nlist = (uint32_t)ix->n_lists, exbits = ix->ex_bits;
+    const size_t ref_stride = (size_t)D * 4 + 384, dev_stride = (size_t)Dc * 4 + 384, exb = (size_t)D * exbits / 8;
+    const size_t exd = ex_bytes_dev(D, exbits);
+    std::vector<uint32_t> gb0(nlist), ln(nlist);
+    uint64_t nblocks = 0, nvec = 0;
+    for (uint32_t c = 0; c < nlist; ++c) {
+        const ListSrc& L = lists[c];
+        if (L.n > 0xffffffffull) return fail(RBQ_INVALID_CONFIG, "list too large");
+        gb0[c] = (uint32_t)nblocks; ln[c] = (uint32_t)L.n;
+        nblocks += (L.n + 31) / 32; nvec += L.n;
+        if (nblocks * 32 > 0xffffffffull) return fail(RBQ_INVALID_CONFIG, "index too large for 32-bit vector slots");
+    }
+    ix->n_blocks = nblocks; ix->n_vectors = nvec;
+    const uint64_t nslots = nblocks * 32;
+    int rc;
+    if ((rc = upload_arr(ix->rot_blob, hdr->rotator_blob, hdr->rotator_len))) return rc;
+    if ((rc = upload_arr(ix->list_gb0, gb0.data(), (size_t)nlist * 4))) return rc;
+    if ((rc = upload_arr(ix->list_n, ln.data(), (size_t)nlist * 4))) return rc;
+    {
+        std::vector<float> cent((size_t)nlist * D);
+        for (uint32_t c = 0; c < nlist; ++c) std::memcpy(&cent[(size_t)c * D], lists[c].centroid, (size_t)D * 4);
+        if ((rc = upload_arr(ix->centroids, cent.data(), cent.size() * 4))) return rc;
+    }
+    if ((rc = alloc_arr(ix->blocks, nblocks * dev_stride))) return rc;
+    if ((rc = alloc_arr(ix->ids, nslots * 8))) return rc;
+    if ((rc = alloc_arr(ix->ex, exd ? nslots * exd + 256 : 0))) return rc;
+    if ((rc = alloc_arr(ix->fadd_ex, exbits ? nslots * 4 : 0))) return rc;
+    if ((rc = alloc_arr(ix->fres_ex, exbits ? nslots * 4 : 0))) return rc;
+    if ((rc = alloc_arr(ix->bsum, nblocks * sizeof(BlockSummary)))) return rc;
+
+    // Chunks of whole blocks (a long list may span several), staged through two pinned buffers: the host fills
+    // one while the GPU converts the other.  Staging layout (16-byte aligned sections):
+    //   recs [nb][ref_stride] | ex [nv][exb] | ids [nv] u64 | fadd [nv] f32 | fres [nv] f32 | dense0 [nb] u64 | nvb [nb] u32
+    const size_t per_block = ref_stride + 32 * (exb + 16) + 12 + 64;
+    uint64_t chunk_blocks = std::max<uint64_t>(1, ((size_t)64 << 20) / per_block);
+    chunk_blocks = std::min<uint64_t>(chunk_blocks, std::max<uint64_t>(nblocks, 1));
+    const size_t cap = align_up(chunk_blocks * ref_stride, 16) + align_up(chunk_blocks * 32 * exb, 16) + chunk_blocks * 32 * 16 +
+                       chunk_blocks * 12 + 256;
+    uint8_t* pin[2] = {nullptr, nullptr};
+    uint8_t* dst[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(hipStreamCreateWithFlags(&cl.st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipHostMalloc((void**)&pin[i], cap, hipHostMallocDefault)); cl.pin_tmp.push_back(pin[i]);
+        HIP_TRY(hipMalloc((void**)&dst[i], cap)); cl.dev_tmp.push_back(dst[i]);
+        HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); cl.evs.push_back(ev[i]);
+    }
+    uint32_t c = 0;      // list cursor
+    uint64_t lb = 0;     // next block inside list c
+    uint64_t b0 = 0;     // first global block of the chunk
+    int turn = 0;
+    while (b0 < nblocks) {
+        const uint64_t nb = std::min<uint64_t>(chunk_blocks, nblocks - b0);
+        const int i = turn & 1;
+        if (turn >= 2) HIP_TRY(hipEventSynchronize(ev[i]));
+        uint8_t* base = pin[i];
+        const size_t o_recs = 0, o_ex = align_up(nb * ref_stride, 16);
+        // the number of vectors of the chunk is known only after the walk: lay the dense arrays out for the maximum
+        const size_t o_ids = o_ex + align_up(nb * 32 * exb, 16), o_fadd = o_ids + nb * 32 * 8, o_fres = o_fadd + nb * 32 * 4,
+                     o_d0 = o_fres + nb * 32 * 4, o_nv = o_d0 + nb * 8, total = o_nv + nb * 4;
+        uint64_t* dense0 = reinterpret_cast<uint64_t*>(base + o_d0);
+        uint32_t* nvb = reinterpret_cast<uint32_t*>(base + o_nv);
+        uint64_t filled = 0, dense = 0;
+        while (filled < nb) {
+            while (c < nlist && lb >= ((uint64_t)ln[c] + 31) / 32) { ++c; lb = 0; }
+            const ListSrc& L = lists[c];
+            const uint64_t lnb = ((uint64_t)ln[c] + 31) / 32, take = std::min<uint64_t>(lnb - lb, nb - filled);
+            const uint64_t v0 = lb * 32, v1 = std::min<uint64_t>(L.n, (lb + take) * 32), nv = v1 - v0;
+            std::memcpy(base + o_recs + filled * ref_stride, L.batch_data + lb * ref_stride, take * ref_stride);
+            if (nv) std::memcpy(base + o_ids + dense * 8, L.ids + v0 * 8, nv * 8);
+            if (exbits && nv) {
+                if (L.ex_stride == exb) std::memcpy(base + o_ex + dense * exb, L.ex + v0 * exb, nv * exb);
+                else for (uint64_t v = 0; v < nv; ++v) std::memcpy(base + o_ex + (dense + v) * exb, L.ex + (v0 + v) * L.ex_stride, exb);
+                std::memcpy(base + o_fadd + dense * 4, L.fadd + v0 * 4, nv * 4);
+                std::memcpy(base + o_fres + dense * 4, L.fres + v0 * 4, nv * 4);
+            }
+            for (uint64_t b = 0; b < take; ++b) {
+                dense0[filled + b] = dense + b * 32;
+                nvb[filled + b] = (uint32_t)std::min<uint64_t>(32, L.n - (lb + b) * 32);
+            }
+            filled += take; dense += nv; lb += take;
+        }
+        uint8_t* d = dst[i];
+        HIP_TRY(hipMemcpyAsync(d, base, total, hipMemcpyHostToDevice, cl.st));
+        const uint64_t* d_d0 = reinterpret_cast<const uint64_t*>(d + o_d0);
+        const uint32_t* d_nv = reinterpret_cast<const uint32_t*>(d + o_nv);
+        uint8_t* oblocks = (uint8_t*)ix->blocks.p + b0 * dev_stride;
+        HIP_TRY(launch_relayout_blocks(d + o_recs, (uint32_t)nb, D, Dc, oblocks, cl.st));
+        HIP_TRY(launch_block_summary(oblocks, d_nv, (uint32_t)nb, Dc, (BlockSummary*)ix->bsum.p + b0, cl.st));
+        HIP_TRY(launch_spread_u64(reinterpret_cast<const uint64_t*>(d + o_ids), d_d0, d_nv, (uint32_t)nb, ~0ull,
+                                  (uint64_t*)ix->ids.p + b0 * 32, cl.st));
+        if (exbits) {
+            HIP_TRY(launch_relayout_ex(d + o_ex, d_d0, d_nv, (uint32_t)nb, D, exbits, (uint8_t*)ix->ex.p + b0 * 32 * exd, cl.st));
+            HIP_TRY(launch_spread_f32(reinterpret_cast<const float*>(d + o_fadd), d_d0, d_nv, (uint32_t)nb, 0.0f,
+                                      (float*)ix->fadd_ex.p + b0 * 32, cl.st));
+            HIP_TRY(launch_spread_f32(reinterpret_cast<const float*>(d + o_fres), d_d0, d_nv, (uint32_t)nb, 0.0f,
+                                      (float*)ix->fres_ex.p + b0 * 32, cl.st));
+        }
+        HIP_TRY(hipEventRecord(ev[i], cl.st));
+        b0 += nb;
+        ++turn;
+    }
+    if (exd) HIP_TRY(hipMemsetAsync((uint8_t*)ix->ex.p + nslots * exd, 0, 256, cl.st)); // read-ahead pad of the refine loads
+    HIP_TRY(hipStreamSynchronize(cl.st));
+    if ((rc = finish_replica(ix, ln))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = ix;
+    cl.ix = nullptr; // keep
+    // (cl's reference member now refers to a null local copy: nothing freed)
     return RBQ_OK;
 }
 
@@ -272,106 +482,99 @@ int create_impl(const rbq_header* hdr, const rbq_list_view* lists, int n_devices
     *out = nullptr;
     int rc = validate_header(hdr);
     if (rc) return rc;
-    if (n_devices != 1) return fail(RBQ_INVALID_CONFIG, "n_devices must be 1 (one handle per GPU; shard queries across handles)");
     if (!lists) return fail(RBQ_INVALID_CONFIG, "null lists");
+    std::vector<int> devs;
+    if ((rc = resolve_devices(n_devices, devices, devs))) return rc;
+    const size_t ref_stride = (size_t)hdr->padded_dim * 4 + 384, exb = (size_t)hdr->padded_dim * hdr->ex_bits / 8;
+    std::vector<ListSrc> src(hdr->n_lists);
+    for (uint64_t c = 0; c < hdr->n_lists; ++c) {
+        const rbq_list_view& L = lists[c];
+        if (L.n > 0xffffffffull) return fail(RBQ_INVALID_CONFIG, "list too large");
+        const uint64_t nb = (L.n + 31) / 32;
+        if (L.batch_len != nb * ref_stride)
+            return fail(RBQ_INVALID_PERSISTENCE, "batch_data length mismatch - possible corruption or version incompatibility");
+        if (L.n && (!L.centroid || !L.ids || !L.batch_data || (hdr->ex_bits && (!L.ex_codes || !L.f_add_ex || !L.f_rescale_ex))))
+            return fail(RBQ_INVALID_CONFIG, "null list array");
+        if (!L.centroid) return fail(RBQ_INVALID_CONFIG, "null centroid");
+        ListSrc& S = src[c];
+        S.centroid = (const uint8_t*)L.centroid; S.n = L.n; S.ids = (const uint8_t*)L.ids; S.batch_data = L.batch_data;
+        S.ex = L.ex_codes; S.ex_stride = exb; S.fadd = (const uint8_t*)L.f_add_ex; S.fres = (const uint8_t*)L.f_rescale_ex;
+    }
+    Replica* first = nullptr;
+    if ((rc = create_from_sources(hdr, src, devs[0], &first))) return rc;
+    return wrap_and_replicate(first, devs, out);
+}
 
-    int dev = 0;
-    if (devices) dev = devices[0];
-    else HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipSetDevice(dev));
+// ---- GPU-side encoder: the device analogue of train_with_clusters' quantisation loop ------------------------------
+struct TempDev { // device scratch freed on scope exit
+    std::vector<void*> ptrs;
+    hipError_t alloc(void** p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) ptrs.push_back(*p); return e; }
+    ~TempDev() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+};
+struct ReplicaOwner { // frees a half-built replica on an early return
+    Replica* ix;
+    ~ReplicaOwner() { if (ix) free_replica(ix); }
+    Replica* release() { Replica* r = ix; ix = nullptr; return r; }
+};
 
-    rbq_index* ix = new rbq_index();
-    ix->device = dev;
-    ix->dim = hdr->dim; ix->D = hdr->padded_dim; ix->Dc = (hdr->padded_dim + 63u) / 64u * 64u;
-    ix->metric = hdr->metric; ix->rotator = hdr->rotator; ix->ex_bits = hdr->ex_bits;
-    ix->n_lists = hdr->n_lists;
-    ix->trunc = 1u << floor_log2_u32(hdr->dim);
-    ix->fac = 1.0f / std::sqrt((float)ix->trunc);
-
-    const uint32_t D = ix->D, Dc = ix->Dc;
-    const size_t ref_stride = (size_t)D * 4 + 384, dev_stride = (size_t)Dc * 4 + 384, exb = (size_t)D * ix->ex_bits / 8;
-    const size_t exd = ex_bytes_dev(D, ix->ex_bits);
-    std::vector<uint32_t> gb0(ix->n_lists), ln(ix->n_lists);
+// rotated centroids + list geometry + final arrays of an index that the encoder fills (shared by the one-shot and the
+// streamed build).  `counts` = vectors per list.
+int encoder_prepare(Replica* ix, const rbq_header* hdr, const float* centroids, const std::vector<uint32_t>& ln,
+                    std::vector<uint32_t>& gb0, bool zero_fill) {
+    const uint32_t D = ix->D, Dc = ix->Dc, dim = ix->dim, nlist = (uint32_t)ix->n_lists;
+    const size_t dev_stride = (size_t)Dc * 4 + 384, exd = ex_bytes_dev(D, ix->ex_bits);
+    int rc;
+    if ((rc = upload_arr(ix->rot_blob, hdr->rotator_blob, hdr->rotator_len))) return rc;
+    {
+        TempDev t;
+        float* d_craw = nullptr;
+        HIP_TRY(t.alloc((void**)&d_craw, (size_t)nlist * dim * 4));
+        HIP_TRY(hipMemcpy(d_craw, centroids, (size_t)nlist * dim * 4, hipMemcpyHostToDevice));
+        if ((rc = alloc_arr(ix->centroids, (size_t)nlist * D * 4))) return rc;
+        HIP_TRY(launch_rotate_rows(d_craw, nullptr, nlist, dim, D, (int)ix->rotator, (const uint8_t*)ix->rot_blob.p, ix->trunc, ix->fac,
+                                   (float*)ix->centroids.p, 0));
+        HIP_TRY(hipDeviceSynchronize());
+    }
     uint64_t nblocks = 0, nvec = 0;
-    for (uint64_t c = 0; c < ix->n_lists; ++c) {
-        const rbq_list_view& L = lists[c];
-        if (L.n > 0xffffffffull) { free_index(ix); return fail(RBQ_INVALID_CONFIG, "list too large"); }
-        const uint64_t nb = (L.n + 31) / 32;
-        if (L.batch_len != nb * ref_stride) { free_index(ix); return fail(RBQ_INVALID_PERSISTENCE, "batch_data length mismatch - possible corruption or version incompatibility"); }
-        if (L.n && (!L.centroid || !L.ids || !L.batch_data || (ix->ex_bits && (!L.ex_codes || !L.f_add_ex || !L.f_rescale_ex)))) {
-            free_index(ix); return fail(RBQ_INVALID_CONFIG, "null list array");
-        }
-        if (!L.centroid) { free_index(ix); return fail(RBQ_INVALID_CONFIG, "null centroid"); }
-        gb0[c] = (uint32_t)nblocks; ln[c] = (uint32_t)L.n;
-        nblocks += nb; nvec += L.n;
+    gb0.resize(nlist);
+    for (uint32_t c = 0; c < nlist; ++c) {
+        gb0[c] = (uint32_t)nblocks; nblocks += (ln[c] + 31u) / 32u; nvec += ln[c];
+        if (nblocks * 32 > 0xffffffffull) return fail(RBQ_INVALID_CONFIG, "index too large for 32-bit vector slots");
     }
-    if (nblocks * 32 > 0xffffffffull) { free_index(ix); return fail(RBQ_INVALID_CONFIG, "index too large for 32-bit vector slots"); }
-    ix->n_blocks = nblocks; ix->n_vectors = nvec; ix->h_list_n = ln;
-
-    // host staging in device layout
-    std::vector<float> cent((size_t)ix->n_lists * D);
-    std::vector<uint8_t> blocks(nblocks * dev_stride);
-    std::vector<uint64_t> ids(nblocks * 32, ~0ull);
-    std::vector<uint8_t> ex(exd ? nblocks * 32 * exd + 256 : 0);
-    std::vector<float> fa(ix->ex_bits ? nblocks * 32 : 0), fr(ix->ex_bits ? nblocks * 32 : 0);
-    std::vector<BlockSummary> bsum(nblocks);
-    for (uint64_t c = 0; c < ix->n_lists; ++c) {
-        const rbq_list_view& L = lists[c];
-        std::memcpy(&cent[c * D], L.centroid, sizeof(float) * D);
-        const uint64_t nb = (L.n + 31) / 32;
-        for (uint64_t b = 0; b < nb; ++b) {
-            relayout_block(L.batch_data + b * ref_stride, D, Dc, &blocks[(gb0[c] + b) * dev_stride]);
-            // factor ranges over the block's real vectors (block-level lower bound of k_scan)
-            float fac[96];
-            std::memcpy(fac, L.batch_data + b * ref_stride + (size_t)D * 4, 384);
-            const uint32_t nv = (uint32_t)std::min<uint64_t>(32, L.n - b * 32);
-            BlockSummary bs;
-            bs.fadd_min = bs.fres_min = bs.ferr_min = INFINITY;
-            bs.fadd_max = bs.fres_max = bs.ferr_max = -INFINITY;
-            bs.usable = 1; bs.pad = 0;
-            for (uint32_t v = 0; v < nv; ++v) {
-                const float a = fac[v], r = fac[32 + v], e = fac[64 + v];
-                if (!std::isfinite(a) || !std::isfinite(r) || !std::isfinite(e)) bs.usable = 0;
-                bs.fadd_min = std::min(bs.fadd_min, a); bs.fadd_max = std::max(bs.fadd_max, a);
-                bs.fres_min = std::min(bs.fres_min, r); bs.fres_max = std::max(bs.fres_max, r);
-                bs.ferr_min = std::min(bs.ferr_min, e); bs.ferr_max = std::max(bs.ferr_max, e);
-            }
-            if (!bs.usable) { bs.fadd_min = bs.fadd_max = bs.fres_min = bs.fres_max = bs.ferr_min = bs.ferr_max = 0.0f; }
-            bsum[gb0[c] + b] = bs;
-        }
-        const size_t s0 = (size_t)gb0[c] * 32;
-        if (L.n) {
-            std::memcpy(&ids[s0], L.ids, L.n * 8);
-            if (ix->ex_bits) {
-                for (uint64_t v = 0; v < L.n; ++v) relayout_ex(L.ex_codes + v * exb, D, ix->ex_bits, &ex[(s0 + v) * exd]);
-                std::memcpy(&fa[s0], L.f_add_ex, L.n * 4);
-                std::memcpy(&fr[s0], L.f_rescale_ex, L.n * 4);
-            }
-        }
+    ix->n_blocks = nblocks; ix->n_vectors = nvec;
+    const uint64_t nslots = nblocks * 32;
+    if ((rc = upload_arr(ix->list_gb0, gb0.data(), (size_t)nlist * 4))) return rc;
+    if ((rc = upload_arr(ix->list_n, ln.data(), (size_t)nlist * 4))) return rc;
+    if ((rc = alloc_arr(ix->blocks, nblocks * dev_stride))) return rc;
+    HIP_TRY(hipMemset(ix->blocks.p, 0, nblocks * dev_stride));
+    if ((rc = alloc_arr(ix->ids, nslots * 8))) return rc;
+    if ((rc = alloc_arr(ix->ex, exd ? nslots * exd + 256 : 0))) return rc;
+    if ((rc = alloc_arr(ix->fadd_ex, ix->ex_bits ? nslots * 4 : 0))) return rc;
+    if ((rc = alloc_arr(ix->fres_ex, ix->ex_bits ? nslots * 4 : 0))) return rc;
+    if ((rc = alloc_arr(ix->bsum, nblocks * sizeof(BlockSummary)))) return rc;
+    if (exd) HIP_TRY(hipMemset((uint8_t*)ix->ex.p + nslots * exd, 0, 256));
+    if (zero_fill) { // streamed build: padding slots are never visited by the scatter kernels
+        HIP_TRY(hipMemset(ix->ids.p, 0xff, nslots * 8));
+        if (exd) HIP_TRY(hipMemset(ix->ex.p, 0, nslots * exd));
+        if (ix->ex_bits) { HIP_TRY(hipMemset(ix->fadd_ex.p, 0, nslots * 4)); HIP_TRY(hipMemset(ix->fres_ex.p, 0, nslots * 4)); }
     }
-    std::vector<uint8_t> blob;
-    if (hdr->rotator_len) blob.assign(hdr->rotator_blob, hdr->rotator_blob + hdr->rotator_len);
-    std::vector<uint64_t> nblk(ix->n_lists);
-    for (uint64_t c = 0; c < ix->n_lists; ++c) nblk[c] = (ln[c] + 31u) / 32u;
-    std::sort(nblk.begin(), nblk.end(), std::greater<uint64_t>());
-    ix->nblk_desc_prefix.assign(ix->n_lists + 1, 0);
-    for (uint64_t c = 0; c < ix->n_lists; ++c) ix->nblk_desc_prefix[c + 1] = ix->nblk_desc_prefix[c] + nblk[c];
-
-#define UP(dst, vec)                                             \
-    do {                                                         \
-        int _rc = upload(&ix->dst, vec);                         \
-        if (_rc) { free_index(ix); return _rc; }                 \
-    } while (0)
-    UP(d_rot_blob, blob); UP(d_centroids, cent); UP(d_blocks, blocks); UP(d_ids, ids); UP(d_ex, ex);
-    UP(d_fadd_ex, fa); UP(d_fres_ex, fr); UP(d_list_gb0, gb0); UP(d_list_n, ln);
-    UP(d_bsum, bsum);
-    if ((rc = finish_centroid_arrays(ix, cent))) { free_index(ix); return rc; }
-#undef UP
-    *out = ix;
     return RBQ_OK;
 }
 
-// ---- GPU-side encoder (encode.hpp): the device analogue of train_with_clusters' quantisation loop ------------
+// block -> list and block -> number of real vectors, on the device
+int upload_block_tables(const std::vector<uint32_t>& ln, const std::vector<uint32_t>& gb0, uint64_t nblocks, TempDev& t,
+                        uint32_t** d_block_list, uint32_t** d_block_nv) {
+    std::vector<uint32_t> bl(nblocks), bn(nblocks);
+    for (size_t c = 0; c < ln.size(); ++c) {
+        const uint32_t nb = (ln[c] + 31u) / 32u;
+        for (uint32_t b = 0; b < nb; ++b) { bl[gb0[c] + b] = (uint32_t)c; bn[gb0[c] + b] = std::min<uint32_t>(32u, ln[c] - b * 32u); }
+    }
+    HIP_TRY(t.alloc((void**)d_block_list, nblocks * 4)); HIP_TRY(t.alloc((void**)d_block_nv, nblocks * 4));
+    HIP_TRY(hipMemcpy(*d_block_list, bl.data(), nblocks * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(*d_block_nv, bn.data(), nblocks * 4, hipMemcpyHostToDevice));
+    return RBQ_OK;
+}
+
 int build_device_impl(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
                       uint64_t n, float t_const, int dev, rbq_index** out) {
     if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
@@ -382,114 +585,56 @@ int build_device_impl(const rbq_header* hdr, const float* centroids, const float
     if (n == 0) return fail(RBQ_INVALID_CONFIG, "no vectors");
     if (n > 0xfffffff0ull) return fail(RBQ_INVALID_CONFIG, "too many vectors for 32-bit slots");
     if (hdr->ex_bits > 0 && !(t_const > 0.0f)) return fail(RBQ_INVALID_CONFIG, "the device encoder needs the constant rescale factor (faster config)");
-    HIP_TRY(hipSetDevice(dev));
+    std::vector<int> devs;
+    if ((rc = resolve_devices(1, &dev, devs))) return rc;
+    DeviceGuard g(dev);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
 
-    rbq_index* ix = new rbq_index();
-    ix->device = dev;
-    ix->dim = hdr->dim; ix->D = hdr->padded_dim; ix->Dc = (hdr->padded_dim + 63u) / 64u * 64u;
-    ix->metric = hdr->metric; ix->rotator = hdr->rotator; ix->ex_bits = hdr->ex_bits;
-    ix->n_lists = hdr->n_lists;
-    ix->trunc = 1u << floor_log2_u32(hdr->dim);
-    ix->fac = 1.0f / std::sqrt((float)ix->trunc);
+    ReplicaOwner own{new_replica(hdr, dev)};
+    Replica* ix = own.ix;
     const uint32_t D = ix->D, Dc = ix->Dc, dim = ix->dim, nlist = (uint32_t)ix->n_lists;
     const size_t dev_stride = (size_t)Dc * 4 + 384, exd = ex_bytes_dev(D, ix->ex_bits);
-
-    std::vector<void*> temps;
-    auto cleanup = [&](int code) { for (void* p : temps) if (p) (void)hipFree(p); if (code) free_index(ix); return code; };
-#define TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { (void)fail(RBQ_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); return cleanup(RBQ_DEVICE); } } while (0)
-    auto tmp_alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) temps.push_back(*p); return e; };
-
-    std::vector<uint8_t> blob;
-    if (hdr->rotator_len) blob.assign(hdr->rotator_blob, hdr->rotator_blob + hdr->rotator_len);
-    if ((rc = upload(&ix->d_rot_blob, blob))) return cleanup(rc);
-
-    // rotated centroids
-    std::vector<float> cent((size_t)nlist * D);
-    {
-        float* d_craw = nullptr;
-        TRY(tmp_alloc((void**)&d_craw, (size_t)nlist * dim * 4));
-        TRY(hipMemcpy(d_craw, centroids, (size_t)nlist * dim * 4, hipMemcpyHostToDevice));
-        TRY(hipMalloc(&ix->d_centroids, (size_t)nlist * D * 4));
-        hipLaunchKernelGGL(k_rotate_rows, dim3(nlist), dim3(kThreads), (size_t)D * 4 * 2, 0, (const float*)d_craw, (const uint32_t*)nullptr,
-                           dim, D, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (float*)ix->d_centroids);
-        TRY(hipGetLastError());
-        TRY(hipMemcpy(cent.data(), ix->d_centroids, cent.size() * 4, hipMemcpyDeviceToHost));
-    }
+    TempDev t;
 
     // list sizes
-    std::vector<uint32_t> ln(nlist), gb0(nlist);
+    std::vector<uint32_t> ln(nlist), gb0;
     {
         uint32_t* d_counts = nullptr;
-        TRY(tmp_alloc((void**)&d_counts, (size_t)(nlist + 1) * 4));
-        TRY(hipMemset(d_counts, 0, (size_t)(nlist + 1) * 4));
-        hipLaunchKernelGGL(k_count_assign, dim3(1024), dim3(256), 0, 0, d_assign, n, nlist, d_counts, d_counts + nlist);
-        TRY(hipGetLastError());
-        std::vector<uint32_t> hc(nlist + 1);
-        TRY(hipMemcpy(hc.data(), d_counts, hc.size() * 4, hipMemcpyDeviceToHost));
-        if (hc[nlist]) { (void)fail(RBQ_INVALID_CONFIG, "assignment out of range"); return cleanup(RBQ_INVALID_CONFIG); }
+        HIP_TRY(t.alloc((void**)&d_counts, (size_t)(nlist + 1) * 4));
+        HIP_TRY(hipMemset(d_counts, 0, (size_t)(nlist + 1) * 4));
+        HIP_TRY(launch_count_assign(d_assign, n, nlist, d_counts, d_counts + nlist, 0));
+        std::vector<uint32_t> hc((size_t)nlist + 1);
+        HIP_TRY(hipMemcpy(hc.data(), d_counts, hc.size() * 4, hipMemcpyDeviceToHost));
+        if (hc[nlist]) return fail(RBQ_INVALID_CONFIG, "assignment out of range");
         std::copy(hc.begin(), hc.begin() + nlist, ln.begin());
     }
-    uint64_t nblocks = 0;
+    if ((rc = encoder_prepare(ix, hdr, centroids, ln, gb0, /*zero_fill=*/false))) return rc;
+    const uint64_t nblocks = ix->n_blocks, nslots = nblocks * 32;
     std::vector<uint64_t> vstart(nlist);
-    {
-        uint64_t run = 0;
-        for (uint32_t c = 0; c < nlist; ++c) { gb0[c] = (uint32_t)nblocks; vstart[c] = run; nblocks += (ln[c] + 31u) / 32u; run += ln[c]; }
-    }
-    if (nblocks * 32 > 0xffffffffull) { (void)fail(RBQ_INVALID_CONFIG, "index too large for 32-bit vector slots"); return cleanup(RBQ_INVALID_CONFIG); }
-    ix->n_blocks = nblocks; ix->n_vectors = n; ix->h_list_n = ln;
-    {
-        std::vector<uint64_t> nblk(nlist);
-        for (uint32_t c = 0; c < nlist; ++c) nblk[c] = (ln[c] + 31u) / 32u;
-        std::sort(nblk.begin(), nblk.end(), std::greater<uint64_t>());
-        ix->nblk_desc_prefix.assign(nlist + 1, 0);
-        for (uint32_t c = 0; c < nlist; ++c) ix->nblk_desc_prefix[c + 1] = ix->nblk_desc_prefix[c] + nblk[c];
-    }
-    if ((rc = upload(&ix->d_list_gb0, gb0))) return cleanup(rc);
-    if ((rc = upload(&ix->d_list_n, ln))) return cleanup(rc);
-    const uint64_t nslots = nblocks * 32;
+    { uint64_t run = 0; for (uint32_t c = 0; c < nlist; ++c) { vstart[c] = run; run += ln[c]; } }
 
     // stable grouping by list (ascending vector index inside a list, src/ivf.rs:1141-1149): radix sort on the list id
     uint32_t* d_slot_src = nullptr;
     {
         uint32_t *d_ko = nullptr, *d_vi = nullptr, *d_vo = nullptr;
         uint64_t* d_vstart = nullptr;
-        TRY(tmp_alloc((void**)&d_ko, n * 4)); TRY(tmp_alloc((void**)&d_vi, n * 4)); TRY(tmp_alloc((void**)&d_vo, n * 4));
-        TRY(tmp_alloc((void**)&d_vstart, (size_t)nlist * 8));
-        TRY(hipMemcpy(d_vstart, vstart.data(), (size_t)nlist * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_iota, dim3(1024), dim3(256), 0, 0, d_vi, n);
-        TRY(hipGetLastError());
+        HIP_TRY(t.alloc((void**)&d_ko, n * 4)); HIP_TRY(t.alloc((void**)&d_vi, n * 4)); HIP_TRY(t.alloc((void**)&d_vo, n * 4));
+        HIP_TRY(t.alloc((void**)&d_vstart, (size_t)nlist * 8));
+        HIP_TRY(hipMemcpy(d_vstart, vstart.data(), (size_t)nlist * 8, hipMemcpyHostToDevice));
+        HIP_TRY(launch_iota(d_vi, n, 0));
         unsigned bits = 1;
         while ((1ull << bits) < nlist) ++bits;
         size_t tb = 0;
-        TRY(rocprim::radix_sort_pairs(nullptr, tb, d_assign, d_ko, d_vi, d_vo, (size_t)n, 0u, bits, (hipStream_t)0));
+        HIP_TRY(sort_pairs_u32(nullptr, &tb, d_assign, d_ko, d_vi, d_vo, (size_t)n, bits, 0));
         void* d_tmp = nullptr;
-        TRY(tmp_alloc(&d_tmp, tb));
-        TRY(rocprim::radix_sort_pairs(d_tmp, tb, d_assign, d_ko, d_vi, d_vo, (size_t)n, 0u, bits, (hipStream_t)0));
-        TRY(tmp_alloc((void**)&d_slot_src, nslots * 4));
-        TRY(hipMemset(d_slot_src, 0xff, nslots * 4));
-        hipLaunchKernelGGL(k_scatter_slots, dim3(1024), dim3(256), 0, 0, (const uint32_t*)d_ko, (const uint32_t*)d_vo, n,
-                           (const uint32_t*)ix->d_list_gb0, (const uint64_t*)d_vstart, d_slot_src);
-        TRY(hipGetLastError());
+        HIP_TRY(t.alloc(&d_tmp, tb));
+        HIP_TRY(sort_pairs_u32(d_tmp, &tb, d_assign, d_ko, d_vi, d_vo, (size_t)n, bits, 0));
+        HIP_TRY(t.alloc((void**)&d_slot_src, nslots * 4));
+        HIP_TRY(hipMemset(d_slot_src, 0xff, nslots * 4));
+        HIP_TRY(launch_scatter_slots(d_ko, d_vo, n, (const uint32_t*)ix->list_gb0.p, d_vstart, d_slot_src, 0));
     }
-    // block -> list, block -> number of real vectors
     uint32_t *d_block_list = nullptr, *d_block_nv = nullptr;
-    {
-        std::vector<uint32_t> bl(nblocks), bn(nblocks);
-        for (uint32_t c = 0; c < nlist; ++c) {
-            const uint32_t nb = (ln[c] + 31u) / 32u;
-            for (uint32_t b = 0; b < nb; ++b) { bl[gb0[c] + b] = c; bn[gb0[c] + b] = std::min<uint32_t>(32u, ln[c] - b * 32u); }
-        }
-        TRY(tmp_alloc((void**)&d_block_list, nblocks * 4)); TRY(tmp_alloc((void**)&d_block_nv, nblocks * 4));
-        TRY(hipMemcpy(d_block_list, bl.data(), nblocks * 4, hipMemcpyHostToDevice));
-        TRY(hipMemcpy(d_block_nv, bn.data(), nblocks * 4, hipMemcpyHostToDevice));
-    }
-
-    // final arrays
-    TRY(hipMalloc(&ix->d_blocks, nblocks * dev_stride)); TRY(hipMemset(ix->d_blocks, 0, nblocks * dev_stride));
-    TRY(hipMalloc(&ix->d_ids, nslots * 8));
-    TRY(hipMalloc(&ix->d_ex, exd ? nslots * exd + 256 : 16));
-    TRY(hipMalloc(&ix->d_fadd_ex, ix->ex_bits ? nslots * 4 : 16)); TRY(hipMalloc(&ix->d_fres_ex, ix->ex_bits ? nslots * 4 : 16));
-    TRY(hipMalloc(&ix->d_bsum, nblocks * sizeof(BlockSummary)));
+    if ((rc = upload_block_tables(ln, gb0, nblocks, t, &d_block_list, &d_block_nv))) return rc;
 
     // encode, a chunk of blocks at a time (scratch: rotated rows + raw ex codes of the chunk)
     {
@@ -498,58 +643,208 @@ int build_device_impl(const rbq_header* hdr, const float* centroids, const float
         const uint64_t chunk_slots = chunk_blocks * 32;
         float* d_rows = nullptr;
         uint8_t* d_raw = nullptr;
-        TRY(tmp_alloc((void**)&d_rows, chunk_slots * D * 4));
-        TRY(tmp_alloc((void**)&d_raw, ix->ex_bits ? chunk_slots * D : 16));
+        HIP_TRY(t.alloc((void**)&d_rows, chunk_slots * D * 4));
+        HIP_TRY(t.alloc((void**)&d_raw, ix->ex_bits ? chunk_slots * D : 16));
         for (uint64_t b0 = 0; b0 < nblocks; b0 += chunk_blocks) {
             const uint64_t nb = std::min<uint64_t>(chunk_blocks, nblocks - b0), ns = nb * 32, s0 = b0 * 32;
-            hipLaunchKernelGGL(k_rotate_rows, dim3((uint32_t)ns), dim3(kThreads), (size_t)D * 4 * 2, 0, d_data, (const uint32_t*)(d_slot_src + s0),
-                               dim, D, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, d_rows);
-            TRY(hipGetLastError());
+            HIP_TRY(launch_rotate_rows(d_data, d_slot_src + s0, (uint32_t)ns, dim, D, (int)ix->rotator, (const uint8_t*)ix->rot_blob.p,
+                                       ix->trunc, ix->fac, d_rows, 0));
             EncodeParams P;
-            P.rows = d_rows; P.centroids = (const float*)ix->d_centroids; P.slot_src = d_slot_src + s0; P.block_list = d_block_list + b0;
-            P.blocks = (uint8_t*)ix->d_blocks + b0 * dev_stride; P.raw_ex = d_raw;
-            P.f_add_ex = (float*)ix->d_fadd_ex + s0; P.f_rescale_ex = (float*)ix->d_fres_ex + s0; P.ids = (uint64_t*)ix->d_ids + s0;
+            P.rows = d_rows; P.centroids = (const float*)ix->centroids.p; P.slot_src = d_slot_src + s0; P.block_list = d_block_list + b0;
+            P.row_slot = nullptr;
+            P.blocks = (uint8_t*)ix->blocks.p + b0 * dev_stride; P.raw_ex = d_raw;
+            P.f_add_ex = (float*)ix->fadd_ex.p + s0; P.f_rescale_ex = (float*)ix->fres_ex.p + s0; P.ids = (uint64_t*)ix->ids.p + s0;
             P.src_base = 0; P.nslots = (uint32_t)ns; P.D = D; P.Dc = Dc; P.ex_bits = ix->ex_bits; P.metric = ix->metric; P.t_const = t_const;
-            hipLaunchKernelGGL(k_encode, dim3((uint32_t)((ns + kEncThreads - 1) / kEncThreads)), dim3(kEncThreads), 0, 0, P);
-            TRY(hipGetLastError());
-            if (ix->ex_bits) {
-                hipLaunchKernelGGL(k_pack_ex, dim3((uint32_t)((ns + 15) / 16)), dim3(256), 0, 0, (const uint8_t*)d_raw, (const uint32_t*)(d_slot_src + s0),
-                                   (uint32_t)ns, D, (uint32_t)ix->ex_bits, (uint8_t*)ix->d_ex + s0 * exd);
-                TRY(hipGetLastError());
-            }
+            HIP_TRY(launch_encode(P, 0));
+            if (ix->ex_bits)
+                HIP_TRY(launch_pack_ex(d_raw, d_slot_src + s0, nullptr, (uint32_t)ns, D, (uint32_t)ix->ex_bits, (uint8_t*)ix->ex.p + s0 * exd, 0));
         }
-        hipLaunchKernelGGL(k_block_summary, dim3((uint32_t)((nblocks + 7) / 8)), dim3(256), 0, 0, (const uint8_t*)ix->d_blocks,
-                           (const uint32_t*)d_block_nv, (uint32_t)nblocks, Dc, (BlockSummary*)ix->d_bsum);
-        TRY(hipGetLastError());
-        TRY(hipDeviceSynchronize());
+        HIP_TRY(launch_block_summary((const uint8_t*)ix->blocks.p, d_block_nv, (uint32_t)nblocks, Dc, (BlockSummary*)ix->bsum.p, 0));
+        HIP_TRY(hipDeviceSynchronize());
     }
-#undef TRY
-    if ((rc = finish_centroid_arrays(ix, cent))) return cleanup(rc);
-    cleanup(0);
-    *out = ix;
+    if ((rc = finish_replica(ix, ln))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return wrap_and_replicate(own.release(), devs, out);
+}
+
+} // namespace
+
+// ---- streamed build: the same encoder fed chunk by chunk (rbq_build_stream_*) -----------------------------------
+struct rbq_builder {
+    Replica* ix = nullptr;
+    int device = 0;
+    float t_const = 0.0f;
+    std::vector<uint32_t> ln, gb0;
+    uint64_t n_total = 0, pushed = 0, next_id = 0;
+    uint32_t *d_cursor = nullptr, *d_chunk_first = nullptr, *d_block_list = nullptr, *d_block_nv = nullptr, *d_counts = nullptr;
+    DevBuf vec, assign, ko, vi, vo, tmp, row_src, row_slot, rows, raw;
+    TempDev tables;
+    ~rbq_builder() {
+        DeviceGuard g(device);
+        for (DevBuf* b : {&vec, &assign, &ko, &vi, &vo, &tmp, &row_src, &row_slot, &rows, &raw}) b->release();
+        if (ix) free_replica(ix);
+    }
+};
+
+namespace {
+
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice;
+}
+bool is_pinned_host_pointer(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int stream_begin_impl(const rbq_header* hdr, const float* centroids, const uint32_t* list_sizes, float t_const, int dev,
+                      rbq_builder** out) {
+    if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
+    *out = nullptr;
+    int rc = validate_header(hdr);
+    if (rc) return rc;
+    if (!centroids || !list_sizes) return fail(RBQ_INVALID_CONFIG, "null buffer");
+    if (hdr->ex_bits > 0 && !(t_const > 0.0f)) return fail(RBQ_INVALID_CONFIG, "the device encoder needs the constant rescale factor (faster config)");
+    std::vector<int> devs;
+    if ((rc = resolve_devices(1, &dev, devs))) return rc;
+    DeviceGuard g(dev);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    std::unique_ptr<rbq_builder> b(new rbq_builder());
+    b->device = dev; b->t_const = t_const;
+    b->ix = new_replica(hdr, dev);
+    const uint32_t nlist = (uint32_t)hdr->n_lists;
+    b->ln.assign(list_sizes, list_sizes + nlist);
+    for (uint32_t c = 0; c < nlist; ++c) b->n_total += b->ln[c];
+    if (b->n_total == 0) return fail(RBQ_INVALID_CONFIG, "no vectors");
+    if ((rc = encoder_prepare(b->ix, hdr, centroids, b->ln, b->gb0, /*zero_fill=*/true))) return rc;
+    if ((rc = upload_block_tables(b->ln, b->gb0, b->ix->n_blocks, b->tables, &b->d_block_list, &b->d_block_nv))) return rc;
+    HIP_TRY(b->tables.alloc((void**)&b->d_cursor, (size_t)nlist * 4));
+    HIP_TRY(b->tables.alloc((void**)&b->d_chunk_first, (size_t)nlist * 4));
+    HIP_TRY(b->tables.alloc((void**)&b->d_counts, (size_t)(nlist + 1) * 4));
+    HIP_TRY(hipMemset(b->d_cursor, 0, (size_t)nlist * 4));
+    HIP_TRY(hipMemset(b->d_counts, 0, (size_t)(nlist + 1) * 4));
+    *out = b.release();
     return RBQ_OK;
 }
 
-Workspace* take_ws(rbq_index* ix) {
+int stream_push_impl(rbq_builder* b, const float* vectors, const uint32_t* assign, uint64_t first_id, uint64_t count) {
+    if (!b || !b->ix) return fail(RBQ_INVALID_CONFIG, "null builder");
+    if (count == 0) return RBQ_OK;
+    if (!vectors || !assign) return fail(RBQ_INVALID_CONFIG, "null buffer");
+    if (first_id < b->next_id) return fail(RBQ_INVALID_CONFIG, "chunks must be pushed in ascending id order (list membership order, src/ivf.rs:1141-1149)");
+    if (b->pushed + count > b->n_total) return fail(RBQ_INVALID_CONFIG, "more vectors pushed than the list sizes announced");
+    DeviceGuard g(b->device);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    Replica* ix = b->ix;
+    const uint32_t D = ix->D, Dc = ix->Dc, dim = ix->dim, nlist = (uint32_t)ix->n_lists;
+    const size_t exd = ex_bytes_dev(D, ix->ex_bits);
+    const bool vec_dev = is_device_pointer(vectors), asg_dev = is_device_pointer(assign);
+    // sub-chunks bounded by the scratch for the rotated rows (512 MB)
+    const uint64_t SUB = std::max<uint64_t>(1024, ((512ull << 20) / ((size_t)D * 4)) & ~63ull);
+    unsigned bits = 1;
+    while ((1ull << bits) < nlist) ++bits;
+    int rc;
+    for (uint64_t s0 = 0; s0 < count; s0 += SUB) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(SUB, count - s0);
+        const float* d_vec = vectors + s0 * dim;
+        const uint32_t* d_asg = assign + s0;
+        if (!vec_dev) {
+            if ((rc = b->vec.ensure((size_t)n * dim * 4))) return rc;
+            HIP_TRY(hipMemcpy(b->vec.p, vectors + s0 * dim, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+            d_vec = (const float*)b->vec.p;
+        }
+        if (!asg_dev) {
+            if ((rc = b->assign.ensure((size_t)n * 4))) return rc;
+            HIP_TRY(hipMemcpy(b->assign.p, assign + s0, (size_t)n * 4, hipMemcpyHostToDevice));
+            d_asg = (const uint32_t*)b->assign.p;
+        }
+        // counts so far incl. this sub-chunk: no list may outgrow its announced size (its slots are fixed)
+        HIP_TRY(launch_count_assign(d_asg, n, nlist, b->d_counts, b->d_counts + nlist, 0));
+        {
+            std::vector<uint32_t> hc((size_t)nlist + 1);
+            HIP_TRY(hipMemcpy(hc.data(), b->d_counts, hc.size() * 4, hipMemcpyDeviceToHost));
+            if (hc[nlist]) return fail(RBQ_INVALID_CONFIG, "assignment out of range");
+            for (uint32_t c = 0; c < nlist; ++c)
+                if (hc[c] > b->ln[c]) return fail(RBQ_INVALID_CONFIG, "list " + std::to_string(c) + " received more vectors than announced");
+        }
+        if ((rc = b->ko.ensure((size_t)n * 4)) || (rc = b->vi.ensure((size_t)n * 4)) || (rc = b->vo.ensure((size_t)n * 4)) ||
+            (rc = b->row_src.ensure((size_t)n * 4)) || (rc = b->row_slot.ensure((size_t)n * 4)) ||
+            (rc = b->rows.ensure((size_t)n * D * 4)) || (rc = b->raw.ensure(ix->ex_bits ? (size_t)n * D : 16)))
+            return rc;
+        HIP_TRY(launch_iota((uint32_t*)b->vi.p, n, 0));
+        size_t tb = 0;
+        HIP_TRY(sort_pairs_u32(nullptr, &tb, d_asg, (uint32_t*)b->ko.p, (const uint32_t*)b->vi.p, (uint32_t*)b->vo.p, n, bits, 0));
+        if ((rc = b->tmp.ensure(tb))) return rc;
+        HIP_TRY(sort_pairs_u32(b->tmp.p, &tb, d_asg, (uint32_t*)b->ko.p, (const uint32_t*)b->vi.p, (uint32_t*)b->vo.p, n, bits, 0));
+        HIP_TRY(launch_chunk_first((const uint32_t*)b->ko.p, n, b->d_chunk_first, 0));
+        HIP_TRY(launch_chunk_slots((const uint32_t*)b->ko.p, (const uint32_t*)b->vo.p, n, (const uint32_t*)ix->list_gb0.p, b->d_cursor,
+                                   b->d_chunk_first, (uint32_t*)b->row_src.p, (uint32_t*)b->row_slot.p, 0));
+        HIP_TRY(launch_rotate_rows(d_vec, (const uint32_t*)b->row_src.p, n, dim, D, (int)ix->rotator, (const uint8_t*)ix->rot_blob.p,
+                                   ix->trunc, ix->fac, (float*)b->rows.p, 0));
+        EncodeParams P;
+        P.rows = (const float*)b->rows.p; P.centroids = (const float*)ix->centroids.p; P.slot_src = (const uint32_t*)b->row_src.p;
+        P.block_list = b->d_block_list; P.row_slot = (const uint32_t*)b->row_slot.p;
+        P.blocks = (uint8_t*)ix->blocks.p; P.raw_ex = (uint8_t*)b->raw.p;
+        P.f_add_ex = (float*)ix->fadd_ex.p; P.f_rescale_ex = (float*)ix->fres_ex.p; P.ids = (uint64_t*)ix->ids.p;
+        P.src_base = first_id + s0; P.nslots = n; P.D = D; P.Dc = Dc; P.ex_bits = ix->ex_bits; P.metric = ix->metric; P.t_const = b->t_const;
+        HIP_TRY(launch_encode(P, 0));
+        if (ix->ex_bits)
+            HIP_TRY(launch_pack_ex((const uint8_t*)b->raw.p, (const uint32_t*)b->row_src.p, (const uint32_t*)b->row_slot.p, n, D,
+                                   (uint32_t)ix->ex_bits, (uint8_t*)ix->ex.p, 0));
+        (void)exd;
+        HIP_TRY(launch_chunk_advance((const uint32_t*)b->ko.p, n, b->d_chunk_first, b->d_cursor, 0));
+        HIP_TRY(hipDeviceSynchronize()); // the scratch (and a host caller's buffers) are reused by the next sub-chunk
+    }
+    b->pushed += count;
+    b->next_id = first_id + count;
+    return RBQ_OK;
+}
+
+int stream_finish_impl(rbq_builder* b, int n_devices, const int* devices, rbq_index** out) {
+    if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
+    *out = nullptr;
+    if (!b || !b->ix) return fail(RBQ_INVALID_CONFIG, "null builder");
+    if (b->pushed != b->n_total) return fail(RBQ_INVALID_CONFIG, "list sizes do not match the pushed vectors");
+    std::vector<int> devs;
+    int rc;
+    if (n_devices <= 1 && !devices) devs.push_back(b->device);
+    else if ((rc = resolve_devices(n_devices, devices, devs))) return rc;
+    if (devs[0] != b->device) return fail(RBQ_INVALID_CONFIG, "devices[0] must be the device the builder was opened on");
+    DeviceGuard g(b->device);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    Replica* ix = b->ix;
+    HIP_TRY(launch_block_summary((const uint8_t*)ix->blocks.p, b->d_block_nv, (uint32_t)ix->n_blocks, ix->Dc, (BlockSummary*)ix->bsum.p, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = finish_replica(ix, b->ln))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    b->ix = nullptr;
+    return wrap_and_replicate(ix, devs, out);
+}
+
+// ---- search ---------------------------------------------------------------------------------------------------------
+Workspace* take_ws(Replica* ix) {
     {
         std::lock_guard<std::mutex> g(ix->mu);
         if (!ix->pool.empty()) { Workspace* w = ix->pool.back(); ix->pool.pop_back(); return w; }
     }
     Workspace* w = new Workspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    if (hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(w->stream); delete w; return nullptr; }
     return w;
 }
-void give_ws(rbq_index* ix, Workspace* w) {
+void give_ws(Replica* ix, Workspace* w) {
     std::lock_guard<std::mutex> g(ix->mu);
     ix->pool.push_back(w);
 }
 
 struct ProfScope {
-    rbq_index* ix; int stage; hipStream_t s; std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    Replica* ix; int stage; hipStream_t s; std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     bool on = false, ext = false;
     // ext: the launch itself carries the event pair (hipExtLaunchKernelGGL: start/stop come from the dispatch
     // packet, no separate marker packets in the queue); otherwise the pair is recorded around the scope
-    ProfScope(rbq_index* ix_, int st, hipStream_t s_, bool ext_ = false) : ix(ix_), stage(st), s(s_), ext(ext_) {
+    ProfScope(Replica* ix_, int st, hipStream_t s_, bool ext_ = false) : ix(ix_), stage(st), s(s_), ext(ext_) {
         if (ix->profiling && ((ix->prof_mask >> st) & 1u)) {
             {
                 std::lock_guard<std::mutex> g(ix->mu);
@@ -564,62 +859,36 @@ struct ProfScope {
         if (on) {
             if (!ext) (void)hipEventRecord(ev.second, s);
             std::lock_guard<std::mutex> g(ix->mu);
-            ix->prof[stage].ev.push_back(ev);
+            ix->stage_prof[stage].ev.push_back(ev);
         }
     }
 };
 
-template <int DT, int EX>
-hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (lds > 48 * 1024) { // default dynamic-LDS limit covers the common case; raising it is a driver call
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<DT, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    if (ev0) hipExtLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, ev0, ev1, 0, P);
-    else hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
-    return hipGetLastError();
-}
-template <int DT>
-hipError_t launch_scan(const ScanParams& P, uint32_t nq, size_t lds, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (DT == 0) return launch_scan_t<0, 0>(P, nq, lds, s, ev0, ev1);
-    switch (P.ex_bits) {
-        case 0: return launch_scan_t<DT, 0>(P, nq, lds, s, ev0, ev1);
-        case 2: return launch_scan_t<DT, 2>(P, nq, lds, s, ev0, ev1);
-        default: return launch_scan_t<DT, 6>(P, nq, lds, s, ev0, ev1);
-    }
-}
-
 // k_scan launch shared by the IVF search and the MSTG posting-list scan
-int scan_stage(rbq_index* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, uint32_t top_k, uint64_t wl_stride,
+int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, uint32_t top_k, uint64_t wl_stride,
                const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
                rbq_diag* d_diag, bool mstg, hipStream_t stream) {
-    const uint32_t D = ix->D, Dc = ix->Dc;
     ProfScope ps(ix, 3, stream, /*ext=*/true);
     ScanParams P;
-    P.blocks = (const uint8_t*)ix->d_blocks; P.ids = (const uint64_t*)ix->d_ids; P.ex_codes = (const uint8_t*)ix->d_ex;
-    P.f_add_ex = (const float*)ix->d_fadd_ex; P.f_rescale_ex = (const float*)ix->d_fres_ex;
+    P.blocks = (const uint8_t*)ix->blocks.p; P.ids = (const uint64_t*)ix->ids.p; P.ex_codes = (const uint8_t*)ix->ex.p;
+    P.f_add_ex = (const float*)ix->fadd_ex.p; P.f_rescale_ex = (const float*)ix->fres_ex.p;
     P.lut = (const uint8_t*)w->lut.p; P.rot = (const float*)w->rot.p; P.consts = (const QueryConsts*)w->consts.p;
     P.probe = (const ProbeInfo*)w->probe.p; P.wl = (const StreamItem*)w->wl.p; P.nstream = (const uint32_t*)w->nstream.p;
     P.filter = d_filter; P.filter_nbits = filter_nbits; P.wl_stride = wl_stride;
     P.out_ids = d_ids; P.out_scores = d_scores; P.out_counts = d_counts; P.diag = (unsigned long long*)d_diag;
-    P.D = D; P.Dc = Dc; P.nprobe = probe_stride; P.top_k = top_k; P.metric = ix->metric;
+    P.D = ix->D; P.Dc = ix->Dc; P.nprobe = probe_stride; P.top_k = top_k; P.metric = ix->metric;
     P.ex_bits = mstg ? 0u : ix->ex_bits; // MSTG search never evaluates the ex codes (src/mstg/index.rs:216-330)
     P.no_block_bound = ix->no_block_bound ? 1u : 0u;
     P.exact_heap = ix->exact_heap ? 1u : 0u;
-    P.heap_restarts = (unsigned int*)ix->d_fallbacks + 1;
+    P.heap_restarts = (unsigned int*)ix->fallbacks.p + 1;
     P.mstg = mstg ? 1u : 0u;
-    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, top_k);
-    hipError_t e;
-    if (D == Dc && D == 960) e = launch_scan<960>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
-    else if (D == Dc && D == 768) e = launch_scan<768>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
-    else if (D == Dc && D == 128) e = launch_scan<128>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
-    else e = launch_scan<0>(P, (uint32_t)nq, lds, stream, ps.start(), ps.stop());
-    HIP_TRY(e);
+    P.prof = ix->profiling ? (unsigned long long*)ix->prof.p : nullptr;
+    HIP_TRY(launch_scan(P, (uint32_t)nq, ix->device, stream, ps.start(), ps.stop()));
     return RBQ_OK;
 }
 
 // Core: everything on device pointers, enqueued on `stream`. Workspace buffers come from `w`.
-int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t nq, uint32_t top_k, uint32_t nprobe_in,
+int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq, uint32_t top_k, uint32_t nprobe_in,
                   const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
                   rbq_diag* d_diag, hipStream_t stream) {
     const uint32_t D = ix->D, Dc = ix->Dc;
@@ -628,7 +897,7 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
     if (nprobe > nlist) nprobe = nlist;
     if (nprobe > 4096) return fail(RBQ_INVALID_CONFIG, "nprobe > 4096 is not supported by the GPU probe selector");
     if (top_k > 4096) return fail(RBQ_INVALID_CONFIG, "top_k > 4096 is not supported by the GPU top-k stage");
-    const uint32_t np2 = next_pow2(nprobe);
+    if (ix->rerank && top_k > 1024) return fail(RBQ_INVALID_CONFIG, "rerank supports top_k <= 1024");
     const uint64_t wl_stride = std::max<uint64_t>(ix->nblk_desc_prefix[nprobe], 1);
 
     int rc;
@@ -645,124 +914,171 @@ int search_device(rbq_index* ix, Workspace* w, const float* d_queries, uint64_t 
         if ((rc = w->rot_hi.ensure(nq * D * 2))) return rc;
         if ((rc = w->rot_lo.ensure(nq * D * 2))) return rc;
     }
-
+    unsigned long long* prof = ix->profiling ? (unsigned long long*)ix->prof.p : nullptr;
     {
         ProfScope ps(ix, 0, stream);
-        if (ix->rotator == RBQ_ROTATOR_MATRIX || ix->wg_prep) { // O(D^2) matrix rotation: one workgroup per query
-            const size_t lds = (size_t)D * 4 * 2;
-            hipLaunchKernelGGL(k_prep, dim3((uint32_t)nq), dim3(kThreads), lds, stream, d_queries, ix->dim, D, Dc, (int)ix->rotator,
-                               (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p,
-                               (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p, split_rank ? (uint16_t*)w->rot_hi.p : nullptr,
-                               split_rank ? (uint16_t*)w->rot_lo.p : nullptr);
-        } else { // FHT-Kac / identity: one wave per query
-            const uint32_t qpw = kThreads / 64;
-            hipLaunchKernelGGL(k_prep_wave, dim3((uint32_t)((nq + qpw - 1) / qpw)), dim3(kThreads), (size_t)D * 4 * 2 * qpw + D / 2, stream,
-                               d_queries, (uint32_t)nq, ix->dim, D, Dc, (int)ix->rotator, (const uint8_t*)ix->d_rot_blob, ix->trunc,
-                               ix->fac, (uint32_t)ix->ex_bits, (float*)w->rot.p, (uint8_t*)w->lut.p, (QueryConsts*)w->consts.p,
-                               split_rank ? (uint16_t*)w->rot_hi.p : nullptr, split_rank ? (uint16_t*)w->rot_lo.p : nullptr);
-        }
-        HIP_TRY(hipGetLastError());
+        PrepParams p;
+        p.queries = d_queries; p.nq = (uint32_t)nq; p.dim = ix->dim; p.D = D; p.Dc = Dc; p.rotator = (int)ix->rotator;
+        p.rot_blob = (const uint8_t*)ix->rot_blob.p; p.trunc = ix->trunc; p.fac = ix->fac; p.ex_bits = ix->ex_bits;
+        p.rot = (float*)w->rot.p; p.lut = (uint8_t*)w->lut.p; p.consts = (QueryConsts*)w->consts.p;
+        p.rot_hi = split_rank ? (uint16_t*)w->rot_hi.p : nullptr; p.rot_lo = split_rank ? (uint16_t*)w->rot_lo.p : nullptr;
+        p.wg_prep = ix->wg_prep;
+        HIP_TRY(launch_prep(p, ix->device, stream));
     }
+    RankParams rp;
+    rp.metric = ix->metric; rp.rot = (const float*)w->rot.p; rp.rot_hi = (const uint16_t*)w->rot_hi.p; rp.rot_lo = (const uint16_t*)w->rot_lo.p;
+    rp.cent = (const float*)ix->centroids.p; rp.cent_hi = (const uint16_t*)ix->cent_hi.p; rp.cent_lo = (const uint16_t*)ix->cent_lo.p;
+    rp.consts = (const QueryConsts*)w->consts.p; rp.cnorm2 = (const float*)ix->cnorm2.p; rp.nq = (uint32_t)nq; rp.nlist = nlist; rp.D = D;
+    rp.scores = (float*)w->scores.p; rp.split = split_rank;
+    rp.big = !ix->small_rank_tiles && (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
+    SelectParams sp;
+    sp.scores = (float*)w->scores.p; sp.nq = (uint32_t)nq; sp.nlist = nlist; sp.nprobe = nprobe; sp.metric = ix->metric;
+    sp.rot = (const float*)w->rot.p; sp.cent = (const float*)ix->centroids.p; sp.D = D; sp.consts = (const QueryConsts*)w->consts.p;
+    sp.cnorm2_max = ix->cnorm2_max; sp.list_gb0 = (const uint32_t*)ix->list_gb0.p; sp.list_n = (const uint32_t*)ix->list_n.p;
+    sp.probe = (ProbeInfo*)w->probe.p; sp.wl = (StreamItem*)w->wl.p; sp.wl_stride = wl_stride; sp.nstream = (uint32_t*)w->nstream.p;
+    sp.nvec = (unsigned long long*)w->nvec.p; sp.prof_total = prof; sp.fallback_count = (unsigned int*)ix->fallbacks.p;
+    sp.force_fallback = ix->force_rank_fallback ? 1 : 0; sp.bsum = (const BlockSummary*)ix->bsum.p;
     if (ix->exact_rank) {
-        {
-            ProfScope ps(ix, 1, stream);
-            dim3 grid((nlist + 31) / 32, (uint32_t)((nq + 31) / 32));
-            if (ix->metric == 0)
-                hipLaunchKernelGGL(k_rank_scores<0>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
-                                   (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
-            else
-                hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, stream, (const float*)w->rot.p,
-                                   (const float*)ix->d_centroids, (uint32_t)nq, nlist, D, (float*)w->scores.p);
-            HIP_TRY(hipGetLastError());
-        }
-        {
-            ProfScope ps(ix, 2, stream);
-            const size_t lds = (size_t)np2 * 8 + (size_t)D * 4 + kThreads * 4;
-            hipLaunchKernelGGL(k_select, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (const float*)w->scores.p, nlist, nprobe,
-                               np2, (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
-                               (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
-                               (StreamItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,
-                               ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr,
-                               (const QueryConsts*)w->consts.p, (const BlockSummary*)ix->d_bsum);
-            HIP_TRY(hipGetLastError());
-        }
+        { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_exact(rp, stream)); }
+        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, stream)); }
     } else {
-        {
-            ProfScope ps(ix, 1, stream); // approximate scores: one MFMA GEMM
-            const bool big = !ix->small_rank_tiles && (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
-            const uint32_t T = big ? 128u : 64u;
-            dim3 grid((nlist + T - 1) / T, (uint32_t)((nq + T - 1) / T));
-            if (split_rank) {
-                // big problems: 128x128 tiles, 8 waves (each 64x32) — the tile traffic of the 4-wave form with twice
-                // the waves to hide the staging behind the MFMAs; small ones: 64x64 tiles, 4 waves
-#define RBQ_RANK_KERNEL k_rank_bf16_db
-#define RBQ_RANK_LDS(TM, TN, WM, WN) ((size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 80 * 2) /* two slabs of 32, rows of 80 B */
-#define RBQ_LAUNCH_RANKB(M, TM, TN, WM, WN)                                                                            \
-    do {                                                                                                               \
-        const size_t lds = RBQ_RANK_LDS(TM, TN, WM, WN);                                                               \
-        static std::atomic<int> attr_dev_mask{0}; /* once per device: the call is slow and serialises launches */      \
-        if (lds > 48 * 1024 && !(attr_dev_mask.load() & (1 << ix->device))) {                                          \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&RBQ_RANK_KERNEL<M, TM, TN, WM, WN>),            \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-            attr_dev_mask.fetch_or(1 << ix->device);                                                                   \
-        }                                                                                                              \
-        hipLaunchKernelGGL((RBQ_RANK_KERNEL<M, TM, TN, WM, WN>), grid, dim3(64 * WM * WN), lds, stream,                \
-                           (const uint16_t*)w->rot_hi.p, (const uint16_t*)w->rot_lo.p, (const uint16_t*)ix->d_cent_hi, \
-                           (const uint16_t*)ix->d_cent_lo, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2, \
-                           (uint32_t)nq, nlist, D, (float*)w->scores.p);                                               \
-    } while (0)
-                if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANKB(0, 2, 1, 2, 4); else RBQ_LAUNCH_RANKB(0, 1, 1, 2, 2); }
-                else { if (big) RBQ_LAUNCH_RANKB(1, 2, 1, 2, 4); else RBQ_LAUNCH_RANKB(1, 1, 1, 2, 2); }
-#undef RBQ_LAUNCH_RANKB
-            } else {
-#define RBQ_LAUNCH_RANK(M, TW)                                                                                         \
-    hipLaunchKernelGGL((k_rank_mfma<M, TW>), grid, dim3(256), 0, stream, (const float*)w->rot.p,                       \
-                       (const float*)ix->d_centroids, (const QueryConsts*)w->consts.p, (const float*)ix->d_cnorm2,   \
-                       (uint32_t)nq, nlist, D, (float*)w->scores.p)
-            if (ix->metric == 0) { if (big) RBQ_LAUNCH_RANK(0, 2); else RBQ_LAUNCH_RANK(0, 1); }
-            else { if (big) RBQ_LAUNCH_RANK(1, 2); else RBQ_LAUNCH_RANK(1, 1); }
-            }
-#undef RBQ_LAUNCH_RANK
-            HIP_TRY(hipGetLastError());
-        }
-        {
-            ProfScope ps(ix, 2, stream); // shortlist + exact canonical scores + exact select
-            const uint32_t cap2 = std::max<uint32_t>(64u, next_pow2(2 * nprobe));
-            const int row_in_lds = (nlist > 4096 && (size_t)nlist * 4 <= 65536) ? 1 : 0; // <= 4096: registers
-            size_t lds = (size_t)cap2 * 8 + (size_t)D * 4 + kThreads * 4 + (row_in_lds ? (size_t)nlist * 4 : 0);
-            const int stage = lds + (size_t)nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
-            if (stage) lds += (size_t)nprobe * 16;
-#define RBQ_LAUNCH_SELECT(RM)                                                                                         \
-    do {                                                                                                               \
-        if (lds > 48 * 1024)                                                                                           \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_mfma<RM>),                             \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-        hipLaunchKernelGGL(k_select_mfma<RM>, dim3((uint32_t)nq), dim3(kThreads), lds, stream, (float*)w->scores.p,    \
-                           nlist, nprobe, cap2, row_in_lds, (int)ix->metric, (const float*)w->rot.p,                   \
-                           (const float*)ix->d_centroids, D, (const QueryConsts*)w->consts.p, ix->cnorm2_max,          \
-                           (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,     \
-                           (StreamItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (unsigned long long*)w->nvec.p,   \
-                           ix->profiling ? (unsigned long long*)ix->d_prof_total : nullptr,                            \
-                           (unsigned int*)ix->d_fallbacks, ix->force_rank_fallback ? 1 : 0,                            \
-                           (const BlockSummary*)ix->d_bsum, stage);                                                    \
-    } while (0)
-            if (nlist <= 4096) RBQ_LAUNCH_SELECT(2);
-            else if (row_in_lds) RBQ_LAUNCH_SELECT(1);
-            else RBQ_LAUNCH_SELECT(0);
-#undef RBQ_LAUNCH_SELECT
-            HIP_TRY(hipGetLastError());
-        }
+        { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); }           // approximate scores: one MFMA GEMM
+        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
-    return scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
-                      /*mstg=*/false, stream);
+    if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
+                         /*mstg=*/false, stream)))
+        return rc;
+    if (ix->rerank) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
+        HIP_TRY(launch_rerank(d_queries, (uint32_t)nq, ix->dim, (const float*)ix->raw.p, ix->n_raw, ix->metric, top_k, d_ids, d_scores,
+                              d_counts, stream));
     return RBQ_OK;
+}
+
+int check_query_args(const rbq_index* h, uint32_t query_dim) {
+    if (!h || h->reps.empty()) return fail(RBQ_INVALID_CONFIG, "null index");
+    const Replica* ix = h->reps[0];
+    if (ix->n_vectors == 0) return fail(RBQ_EMPTY_INDEX, "index is empty");
+    if (query_dim != ix->dim) {
+        char b[96];
+        std::snprintf(b, sizeof b, "expected %u, got %u", ix->dim, query_dim);
+        return fail(RBQ_DIMENSION_MISMATCH, b);
+    }
+    return RBQ_OK;
+}
+
+// layout of one sub-batch's results in the packed device / pinned buffers
+struct OutPack {
+    size_t o_ids, o_scores, o_counts, o_diag, total;
+    OutPack(uint64_t n, uint32_t top_k, bool diag) {
+        o_ids = 0; o_scores = align_up(n * top_k * 8, 16); o_counts = o_scores + align_up(n * top_k * 4, 16);
+        o_diag = o_counts + align_up(n * 4, 16); total = o_diag + (diag ? n * sizeof(rbq_diag) : 0);
+    }
+};
+
+// rbq_search_batch on ONE replica: the batch is cut into sub-batches that travel through a few lanes (stream +
+// workspace + pinned staging each).  While lane i runs its kernels, the host stages the next sub-batch into lane
+// i+1's pinned buffer and its H2D copy runs; results come back with one D2H per sub-batch into pinned memory and
+// are handed to the caller's arrays when the lane is needed again (or at the end).  Caller buffers that are already
+// page-locked (rbq_host_alloc / hipHostMalloc / hipHostRegister) are used directly, without staging.
+int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
+                const uint32_t* filter_words, uint64_t filter_nbits, uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
+                rbq_diag* diag) {
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    static const uint32_t env_lanes = [] { const char* e = std::getenv("RBQ_HOST_LANES"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    static const uint32_t env_sub = [] { const char* e = std::getenv("RBQ_HOST_SUBBATCH"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    // sub-batch: a quarter of the batch, between 256 and 4096 queries (bounds the nq x nlist score matrix per lane)
+    uint64_t SB = env_sub ? env_sub : std::min<uint64_t>(4096, std::max<uint64_t>(256, align_up((nq + 3) / 4, 64)));
+    SB = std::min<uint64_t>(SB, nq);
+    const uint64_t nsub = (nq + SB - 1) / SB;
+    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, env_lanes ? env_lanes : 4u);
+    const bool in_pinned = is_pinned_host_pointer(queries);
+    const bool out_pinned = is_pinned_host_pointer(out_ids) && is_pinned_host_pointer(out_scores) && is_pinned_host_pointer(out_counts) &&
+                            (!diag || is_pinned_host_pointer(diag));
+    std::vector<Workspace*> lanes;
+    struct Give { Replica* ix; std::vector<Workspace*>& l; bool drained = false;
+                  ~Give() { for (Workspace* w : l) { if (!drained) (void)hipStreamSynchronize(w->stream); give_ws(ix, w); } } } give{ix, lanes};
+    for (uint32_t i = 0; i < nlanes; ++i) {
+        Workspace* w = take_ws(ix);
+        if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
+        lanes.push_back(w);
+    }
+    int rc;
+    const uint32_t* d_filter = nullptr;
+    if (filter_words) {
+        const size_t fb = (size_t)((filter_nbits + 31) / 32) * 4;
+        Workspace* w0 = lanes[0];
+        if ((rc = w0->filter.ensure(fb ? fb : 4))) return rc;
+        if (fb) HIP_TRY(hipMemcpyAsync(w0->filter.p, filter_words, fb, hipMemcpyHostToDevice, w0->stream));
+        HIP_TRY(hipEventRecord(w0->done, w0->stream));
+        for (uint32_t i = 1; i < nlanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i]->stream, w0->done, 0));
+        d_filter = (const uint32_t*)w0->filter.p;
+    }
+    // hand the finished sub-batch j (in lane's pinned buffer) to the caller's arrays
+    auto deliver = [&](Workspace* w, uint64_t j) -> int {
+        HIP_TRY(hipEventSynchronize(w->done));
+        if (out_pinned) return RBQ_OK;
+        const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
+        const OutPack op(n, top_k, diag != nullptr);
+        const uint8_t* src = (const uint8_t*)w->h_out.p;
+        std::memcpy(out_ids + q0 * top_k, src + op.o_ids, n * top_k * 8);
+        std::memcpy(out_scores + q0 * top_k, src + op.o_scores, n * top_k * 4);
+        std::memcpy(out_counts + q0, src + op.o_counts, n * 4);
+        if (diag) std::memcpy(diag + q0, src + op.o_diag, n * sizeof(rbq_diag));
+        return RBQ_OK;
+    };
+    for (uint64_t j = 0; j < nsub; ++j) {
+        Workspace* w = lanes[j % nlanes];
+        if (j >= nlanes && (rc = deliver(w, j - nlanes))) return rc;
+        const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
+        const OutPack op(n, top_k, diag != nullptr);
+        if ((rc = w->queries.ensure(n * query_dim * 4))) return rc;
+        if ((rc = w->out_pack.ensure(op.total))) return rc;
+        const float* src = queries + q0 * query_dim;
+        if (!in_pinned) {
+            if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
+            std::memcpy(w->h_in.p, src, n * query_dim * 4);
+            src = (const float*)w->h_in.p;
+        }
+        HIP_TRY(hipMemcpyAsync(w->queries.p, src, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
+        uint8_t* dp = (uint8_t*)w->out_pack.p;
+        rc = search_device(ix, w, (const float*)w->queries.p, n, top_k, nprobe, d_filter, filter_nbits, (uint64_t*)(dp + op.o_ids),
+                           (float*)(dp + op.o_scores), (uint32_t*)(dp + op.o_counts), diag ? (rbq_diag*)(dp + op.o_diag) : nullptr,
+                           w->stream);
+        if (rc) return rc;
+        if (out_pinned) {
+            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, dp + op.o_ids, n * top_k * 8, hipMemcpyDeviceToHost, w->stream));
+            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, dp + op.o_scores, n * top_k * 4, hipMemcpyDeviceToHost, w->stream));
+            HIP_TRY(hipMemcpyAsync(out_counts + q0, dp + op.o_counts, n * 4, hipMemcpyDeviceToHost, w->stream));
+            if (diag) HIP_TRY(hipMemcpyAsync(diag + q0, dp + op.o_diag, n * sizeof(rbq_diag), hipMemcpyDeviceToHost, w->stream));
+        } else {
+            if ((rc = w->h_out.ensure(op.total))) return rc;
+            HIP_TRY(hipMemcpyAsync(w->h_out.p, dp, op.total, hipMemcpyDeviceToHost, w->stream)); // ONE copy: ids | scores | counts | diag
+        }
+        HIP_TRY(hipEventRecord(w->done, w->stream));
+    }
+    for (uint64_t j = nsub > nlanes ? nsub - nlanes : 0; j < nsub; ++j)
+        if ((rc = deliver(lanes[j % nlanes], j))) return rc;
+    give.drained = true; // every lane's last event has been waited for
+    return RBQ_OK;
+}
+
+Replica* replica_of_pointer(rbq_index* h, const void* dptr) {
+    if (h->reps.size() == 1) return h->reps[0];
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, dptr) == hipSuccess) {
+        for (Replica* r : h->reps) if (r->device == a.device) return r;
+    } else {
+        (void)hipGetLastError();
+    }
+    return h->reps[0];
 }
 
 } // namespace
 
 extern "C" {
 
-uint32_t rbq_abi_version(void) { return (1u << 16) | 0u; }
+uint32_t rbq_abi_version(void) { return (2u << 16) | 0u; }
 
 const char* rbq_strerror(int code) {
     switch (code) {
@@ -788,17 +1104,21 @@ int rbq_last_error_detail(char* buf, size_t n) {
 
 int rbq_index_create(const rbq_header* hdr, const rbq_list_view* lists, int n_devices, const int* devices, rbq_index** out) {
     g_err.clear();
+    RBQ_GUARD_BEGIN
     return create_impl(hdr, lists, n_devices, devices, out);
+    RBQ_GUARD_END
 }
 
-void rbq_index_destroy(rbq_index* ix) { free_index(ix); }
+void rbq_index_destroy(rbq_index* h) { try { free_index(h); } catch (...) {} }
 
-uint64_t rbq_index_len(const rbq_index* ix) { return ix ? ix->n_vectors : 0; }
-uint64_t rbq_index_cluster_count(const rbq_index* ix) { return ix ? ix->n_lists : 0; }
-uint32_t rbq_index_dim(const rbq_index* ix) { return ix ? ix->dim : 0; }
-uint32_t rbq_index_padded_dim(const rbq_index* ix) { return ix ? ix->D : 0; }
+uint64_t rbq_index_len(const rbq_index* h) { return h && !h->reps.empty() ? h->reps[0]->n_vectors : 0; }
+uint64_t rbq_index_cluster_count(const rbq_index* h) { return h && !h->reps.empty() ? h->reps[0]->n_lists : 0; }
+uint32_t rbq_index_dim(const rbq_index* h) { return h && !h->reps.empty() ? h->reps[0]->dim : 0; }
+uint32_t rbq_index_padded_dim(const rbq_index* h) { return h && !h->reps.empty() ? h->reps[0]->D : 0; }
+uint32_t rbq_index_device_count(const rbq_index* h) { return h ? (uint32_t)h->reps.size() : 0; }
 
 // ---- RBQ1 v3 reader: load_from_reader, src/ivf.rs:1484-1702 --------------------------------------
+} // extern "C"
 namespace {
 struct Reader {
     const uint8_t* p; size_t len, off = 0;
@@ -829,11 +1149,10 @@ uint32_t crc32_ieee(const uint8_t* p, size_t n) {
     while (n--) crc = table[0][(crc ^ *p++) & 0xff] ^ (crc >> 8);
     return ~crc;
 }
-} // namespace
 
-int rbq_index_load_rbq1(const void* bytes, size_t len, int n_devices, const int* devices, rbq_index** out) {
-    g_err.clear();
-    if (out) *out = nullptr;
+int load_rbq1_impl(const void* bytes, size_t len, int n_devices, const int* devices, rbq_index** out) {
+    if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
+    *out = nullptr;
     if (!bytes) return fail(RBQ_IO, "null buffer");
     Reader r{(const uint8_t*)bytes, len};
     auto eof = [] { return fail(RBQ_IO, "failed to fill whole buffer"); };
@@ -870,43 +1189,39 @@ int rbq_index_load_rbq1(const void* bytes, size_t len, int n_devices, const int*
     if (cluster_count > (len / 8)) return eof(); // every cluster costs >= 8 bytes; guards the allocation below
     const size_t D = h.padded_dim, stride = D * 4 + 384;
     const size_t exb_expected = h.ex_bits ? D * h.ex_bits / 8 : 0;
-    std::vector<rbq_list_view> lists(cluster_count);
-    std::vector<std::vector<uint8_t>> ex_flat(cluster_count);
-    std::vector<std::vector<float>> fl(cluster_count); // centroid | f_add_ex | f_rescale_ex (alignment-safe copies)
-    std::vector<std::vector<uint64_t>> idv(cluster_count);
+    // the lists are used where they lie in the stream (byte-addressed): nothing is copied on the host but the chunk staging
+    std::vector<ListSrc> lists(cluster_count);
     uint64_t actual = 0;
     for (uint64_t c = 0; c < cluster_count; ++c) {
-        rbq_list_view& L = lists[c];
-        const uint8_t* cen = r.view(D * 4);
-        if (!cen) return eof();
+        ListSrc& L = lists[c];
+        L.centroid = r.view(D * 4);
+        if (!L.centroid) return eof();
         uint64_t n;
         if (!r.take(&n, 8)) return eof();
         if (n > 1000000) return fail(RBQ_INVALID_PERSISTENCE, "cluster size exceeds reasonable limits - possible corruption");
-        const uint8_t* idp = r.view(n * 8);
-        if (!idp) return eof();
+        L.n = n;
+        L.ids = r.view(n * 8);
+        if (!L.ids) return eof();
         uint64_t blen;
         if (!r.take(&blen, 8)) return eof();
         if (blen != ((n + 31) / 32) * stride)
             return fail(RBQ_INVALID_PERSISTENCE, "batch_data length mismatch - possible corruption or version incompatibility");
-        const uint8_t* bd = r.view(blen);
-        if (!bd) return eof();
-        ex_flat[c].resize(n * exb_expected);
+        L.batch_data = r.view(blen);
+        if (!L.batch_data) return eof();
+        L.ex_stride = exb_expected + 8; // every packed code carries a u64 length prefix
         for (uint64_t v = 0; v < n; ++v) {
             uint64_t el;
             if (!r.take(&el, 8)) return eof();
             if (el != exb_expected)
                 return fail(RBQ_INVALID_PERSISTENCE, "ex_code_packed length mismatch - possible corruption or version incompatibility");
-            if (el && !r.take(&ex_flat[c][v * exb_expected], el)) return eof();
+            const uint8_t* e = r.view(el);
+            if (!e) return eof();
+            if (v == 0) L.ex = e;
         }
-        fl[c].resize(D + 2 * n);
-        std::memcpy(fl[c].data(), cen, D * 4);
-        if (!r.take(fl[c].data() + D, n * 4) || !r.take(fl[c].data() + D + n, n * 4)) return eof();
+        L.fadd = r.view(n * 4);
+        L.fres = r.view(n * 4);
+        if (!L.fadd || !L.fres) return eof();
         if (!r.view(n * 4) || !r.view(n * 4)) return eof(); // delta, vl: reconstruction only
-        idv[c].resize(n);
-        std::memcpy(idv[c].data(), idp, n * 8);
-        L.centroid = fl[c].data(); L.n = n; L.ids = idv[c].data(); L.batch_data = bd; L.batch_len = blen;
-        L.ex_codes = ex_flat[c].empty() ? nullptr : ex_flat[c].data();
-        L.f_add_ex = fl[c].data() + D; L.f_rescale_ex = fl[c].data() + D + n;
         actual += n;
     }
     if (actual != expected_vectors) return fail(RBQ_INVALID_PERSISTENCE, "vector count metadata mismatch");
@@ -914,32 +1229,69 @@ int rbq_index_load_rbq1(const void* bytes, size_t len, int n_devices, const int*
     uint32_t stored;
     if (!r.take(&stored, 4)) return eof();
     if (crc32_ieee((const uint8_t*)bytes + 8, body_end - 8) != stored) return fail(RBQ_INVALID_PERSISTENCE, "checksum mismatch");
-    // batch_data records are only byte-addressed by relayout_block (memcpy for the factor rows)
-    return create_impl(&h, lists.data(), n_devices, devices, out);
+    int rc = validate_header(&h); // what this build cannot serve (ex_bits outside {0,2,6}, padded_dim > 2048 ...)
+    if (rc) return rc;
+    std::vector<int> devs;
+    if ((rc = resolve_devices(n_devices, devices, devs))) return rc;
+    Replica* first = nullptr;
+    if ((rc = create_from_sources(&h, lists, devs[0], &first))) return rc;
+    return wrap_and_replicate(first, devs, out);
 }
+} // namespace
+extern "C" {
+
+int rbq_index_load_rbq1(const void* bytes, size_t len, int n_devices, const int* devices, rbq_index** out) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    return load_rbq1_impl(bytes, len, n_devices, devices, out);
+    RBQ_GUARD_END
+}
+
+int rbq_index_build_device(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
+                           uint64_t n, float t_const, int device, rbq_index** out) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    return build_device_impl(hdr, centroids, d_data, d_assign, n, t_const, device, out);
+    RBQ_GUARD_END
+}
+
+int rbq_build_stream_begin(const rbq_header* hdr, const float* centroids, const uint32_t* list_sizes, float t_const, int device,
+                           rbq_builder** out) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    return stream_begin_impl(hdr, centroids, list_sizes, t_const, device, out);
+    RBQ_GUARD_END
+}
+int rbq_build_stream_push(rbq_builder* b, const float* vectors, const uint32_t* assign, uint64_t first_id, uint64_t count) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    return stream_push_impl(b, vectors, assign, first_id, count);
+    RBQ_GUARD_END
+}
+int rbq_build_stream_finish(rbq_builder* b, int n_devices, const int* devices, rbq_index** out) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    int rc = stream_finish_impl(b, n_devices, devices, out);
+    if (rc == RBQ_OK) delete b;
+    return rc;
+    RBQ_GUARD_END
+}
+void rbq_build_stream_abort(rbq_builder* b) { try { delete b; } catch (...) {} }
 
 // ---- search ---------------------------------------------------------------------------------------
-static int check_query_args(const rbq_index* ix, uint32_t query_dim) {
-    if (!ix) return fail(RBQ_INVALID_CONFIG, "null index");
-    if (ix->n_vectors == 0) return fail(RBQ_EMPTY_INDEX, "index is empty");
-    if (query_dim != ix->dim) {
-        char b[96];
-        std::snprintf(b, sizeof b, "expected %u, got %u", ix->dim, query_dim);
-        return fail(RBQ_DIMENSION_MISMATCH, b);
-    }
-    return RBQ_OK;
-}
-
-int rbq_search_batch_device(const rbq_index* cix, const float* d_queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
+int rbq_search_batch_device(const rbq_index* ch, const float* d_queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
                             uint32_t nprobe, const uint32_t* d_filter_words, uint64_t filter_nbits, uint64_t* d_out_ids,
                             float* d_out_scores, uint32_t* d_out_counts, rbq_diag* d_diag, void* hip_stream) {
     g_err.clear();
-    rbq_index* ix = const_cast<rbq_index*>(cix);
-    int rc = check_query_args(ix, query_dim);
+    RBQ_GUARD_BEGIN
+    rbq_index* h = const_cast<rbq_index*>(ch);
+    int rc = check_query_args(h, query_dim);
     if (rc) return rc;
     if (nq == 0) return RBQ_OK;
     if (nq > 0x7fffffffull) return fail(RBQ_INVALID_CONFIG, "batch too large");
-    HIP_TRY(hipSetDevice(ix->device));
+    Replica* ix = replica_of_pointer(h, d_queries);
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
     hipStream_t s = (hipStream_t)hip_stream;
     if (top_k == 0) { // Ok(vec![]) for every query, src/ivf.rs:1792-1794
         HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, s));
@@ -949,21 +1301,40 @@ int rbq_search_batch_device(const rbq_index* cix, const float* d_queries, uint64
     // stream-ordered, so their kernels may share the scratch buffers without any host synchronisation.
     Workspace* w;
     {
-        std::lock_guard<std::mutex> g(ix->mu);
+        std::lock_guard<std::mutex> lk(ix->mu);
         Workspace*& slot = ix->stream_ws[s];
         if (!slot) slot = new Workspace();
         w = slot;
     }
     return search_device(ix, w, d_queries, nq, top_k, nprobe, d_filter_words, filter_nbits, d_out_ids, d_out_scores,
                          d_out_counts, d_diag, s);
+    RBQ_GUARD_END
 }
 
-int rbq_search_batch(const rbq_index* cix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
+int rbq_release_stream(rbq_index* h, void* hip_stream) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    if (!h) return fail(RBQ_INVALID_CONFIG, "null index");
+    for (Replica* ix : h->reps) {
+        Workspace* w = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            auto it = ix->stream_ws.find((hipStream_t)hip_stream);
+            if (it != ix->stream_ws.end()) { w = it->second; ix->stream_ws.erase(it); }
+        }
+        if (w) { DeviceGuard g(ix->device); w->release(); delete w; }
+    }
+    return RBQ_OK;
+    RBQ_GUARD_END
+}
+
+int rbq_search_batch(const rbq_index* ch, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
                      uint32_t nprobe, const uint32_t* filter_words, uint64_t filter_nbits, uint64_t* out_ids,
                      float* out_scores, uint32_t* out_counts, rbq_diag* diag) {
     g_err.clear();
-    rbq_index* ix = const_cast<rbq_index*>(cix);
-    int rc = check_query_args(ix, query_dim);
+    RBQ_GUARD_BEGIN
+    rbq_index* h = const_cast<rbq_index*>(ch);
+    int rc = check_query_args(h, query_dim);
     if (rc) return rc;
     if (nq == 0) return RBQ_OK;
     if (top_k == 0) {
@@ -972,53 +1343,40 @@ int rbq_search_batch(const rbq_index* cix, const float* queries, uint64_t nq, ui
         return RBQ_OK;
     }
     if (!queries || !out_ids || !out_scores || !out_counts) return fail(RBQ_INVALID_CONFIG, "null buffer");
-    HIP_TRY(hipSetDevice(ix->device));
-    Workspace* w = take_ws(ix);
-    if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
-    auto run = [&]() -> int {
-        int r2;
-        const uint64_t CH = 16384; // queries per device pass (bounds the nq x nlist score matrix)
-        if (filter_words) {
-            const size_t fb = (size_t)((filter_nbits + 31) / 32) * 4;
-            if ((r2 = w->filter.ensure(fb ? fb : 4))) return r2;
-            if (fb) HIP_TRY(hipMemcpyAsync(w->filter.p, filter_words, fb, hipMemcpyHostToDevice, w->stream));
-        }
-        for (uint64_t q0 = 0; q0 < nq; q0 += CH) {
-            const uint64_t n = std::min(CH, nq - q0);
-            if ((r2 = w->queries.ensure(n * query_dim * 4))) return r2;
-            if ((r2 = w->out_ids.ensure(n * top_k * 8))) return r2;
-            if ((r2 = w->out_scores.ensure(n * top_k * 4))) return r2;
-            if ((r2 = w->out_counts.ensure(n * 4))) return r2;
-            if (diag && (r2 = w->diag.ensure(n * sizeof(rbq_diag)))) return r2;
-            HIP_TRY(hipMemcpyAsync(w->queries.p, queries + q0 * query_dim, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
-            r2 = search_device(ix, w, (const float*)w->queries.p, n, top_k, nprobe,
-                               filter_words ? (const uint32_t*)w->filter.p : nullptr, filter_nbits, (uint64_t*)w->out_ids.p,
-                               (float*)w->out_scores.p, (uint32_t*)w->out_counts.p, diag ? (rbq_diag*)w->diag.p : nullptr,
-                               w->stream);
-            if (r2) return r2;
-            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, w->out_ids.p, n * top_k * 8, hipMemcpyDeviceToHost, w->stream));
-            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, w->out_scores.p, n * top_k * 4, hipMemcpyDeviceToHost, w->stream));
-            HIP_TRY(hipMemcpyAsync(out_counts + q0, w->out_counts.p, n * 4, hipMemcpyDeviceToHost, w->stream));
-            if (diag) HIP_TRY(hipMemcpyAsync(diag + q0, w->diag.p, n * sizeof(rbq_diag), hipMemcpyDeviceToHost, w->stream));
-            HIP_TRY(hipStreamSynchronize(w->stream));
-        }
-        return RBQ_OK;
+    const size_t R = h->reps.size();
+    if (R == 1 || nq < 2 * R) return search_host(h->reps[0], queries, nq, query_dim, top_k, nprobe, filter_words, filter_nbits, out_ids,
+                                                  out_scores, out_counts, diag);
+    // N replicas: contiguous shards [r*nq/R, (r+1)*nq/R), one host thread per replica (batch_search is a par_iter over
+    // queries, src/ivf.rs:1743-1752); results land straight in the caller's arrays, no exchange between devices
+    std::vector<int> rcs(R, RBQ_OK);
+    std::vector<std::string> details(R);
+    auto shard = [&](size_t r) {
+        const uint64_t q0 = r * nq / R, q1 = (r + 1) * nq / R;
+        try {
+            rcs[r] = search_host(h->reps[r], queries + q0 * query_dim, q1 - q0, query_dim, top_k, nprobe, filter_words, filter_nbits,
+                                 out_ids + q0 * top_k, out_scores + q0 * top_k, out_counts + q0, diag ? diag + q0 : nullptr);
+        } catch (...) { rcs[r] = RBQ_IO; g_err = "internal error"; }
+        details[r] = g_err; // thread-local in the worker
     };
-    rc = run();
-    if (rc) (void)hipStreamSynchronize(w->stream);
-    give_ws(ix, w);
-    return rc;
+    std::vector<std::thread> th;
+    for (size_t r = 1; r < R; ++r) th.emplace_back(shard, r);
+    shard(0);
+    for (auto& t : th) t.join();
+    for (size_t r = 0; r < R; ++r) if (rcs[r]) return fail(rcs[r], details[r]);
+    return RBQ_OK;
+    RBQ_GUARD_END
 }
 
-
 // ---- MSTG posting-list scan ------------------------------------------------------------
-int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
+int rbq_posting_scan_batch(const rbq_index* ch, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k,
                            const uint32_t* list_ids, const uint32_t* list_counts, uint32_t max_lists,
                            uint64_t* out_ids, float* out_scores, uint32_t* out_counts) {
     g_err.clear();
-    rbq_index* ix = const_cast<rbq_index*>(cix);
-    int rc = check_query_args(ix, query_dim);
+    RBQ_GUARD_BEGIN
+    rbq_index* h = const_cast<rbq_index*>(ch);
+    int rc = check_query_args(h, query_dim);
     if (rc) return rc;
+    Replica* ix = h->reps[0];
     if (ix->rotator != RBQ_ROTATOR_NONE) return fail(RBQ_INVALID_CONFIG, "posting-list scan needs an index created with rotator NONE");
     if (nq == 0) return RBQ_OK;
     if (!queries || !list_ids || !list_counts || !out_ids || !out_scores || !out_counts) return fail(RBQ_INVALID_CONFIG, "null buffer");
@@ -1030,7 +1388,8 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
         return RBQ_OK;
     }
     if (max_lists > (1u << 26)) return fail(RBQ_INVALID_CONFIG, "too many lists per query");
-    HIP_TRY(hipSetDevice(ix->device));
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
     // exact work-list bound from the host copy of the list sizes (a list may legally repeat)
     uint64_t wl_stride = 1;
     for (uint64_t q = 0; q < nq; ++q) {
@@ -1053,6 +1412,7 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
         DevBuf& d_cnts = w->nvec;    // reuse: [n] u32
         for (uint64_t q0 = 0; q0 < nq; q0 += CH) {
             const uint64_t n = std::min(CH, nq - q0);
+            const OutPack op(n, top_k, false);
             if ((r2 = w->queries.ensure(n * query_dim * 4))) return r2;
             if ((r2 = w->rot.ensure(n * D * 4))) return r2;
             if ((r2 = w->lut.ensure(n * (size_t)Dc * 4))) return r2;
@@ -1062,37 +1422,38 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
             if ((r2 = w->probe.ensure(n * (size_t)max_lists * sizeof(ProbeInfo)))) return r2;
             if ((r2 = w->wl.ensure(n * wl_stride * sizeof(StreamItem)))) return r2;
             if ((r2 = w->nstream.ensure(n * 4))) return r2;
-            if ((r2 = w->out_ids.ensure(n * top_k * 8))) return r2;
-            if ((r2 = w->out_scores.ensure(n * top_k * 4))) return r2;
-            if ((r2 = w->out_counts.ensure(n * 4))) return r2;
+            if ((r2 = w->out_pack.ensure(op.total))) return r2;
             hipStream_t st = w->stream;
+            uint8_t* dp = (uint8_t*)w->out_pack.p;
             HIP_TRY(hipMemcpyAsync(w->queries.p, queries + q0 * query_dim, n * query_dim * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(d_lists.p, list_ids + q0 * max_lists, n * (size_t)max_lists * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(d_cnts.p, list_counts + q0, n * 4, hipMemcpyHostToDevice, st));
             {
                 ProfScope ps(ix, 0, st);
-                hipLaunchKernelGGL(k_prep_wave, dim3((uint32_t)((n + 3) / 4)), dim3(kThreads), (size_t)D * 4 * 2 * 4 + D / 2, st,
-                                   (const float*)w->queries.p, (uint32_t)n, ix->dim, D, Dc, (int)ix->rotator,
-                                   (const uint8_t*)ix->d_rot_blob, ix->trunc, ix->fac, 0u, (float*)w->rot.p, (uint8_t*)w->lut.p,
-                                   (QueryConsts*)w->consts.p, (uint16_t*)nullptr, (uint16_t*)nullptr);
-                HIP_TRY(hipGetLastError());
+                PrepParams p;
+                p.queries = (const float*)w->queries.p; p.nq = (uint32_t)n; p.dim = ix->dim; p.D = D; p.Dc = Dc; p.rotator = (int)ix->rotator;
+                p.rot_blob = (const uint8_t*)ix->rot_blob.p; p.trunc = ix->trunc; p.fac = ix->fac; p.ex_bits = 0u;
+                p.rot = (float*)w->rot.p; p.lut = (uint8_t*)w->lut.p; p.consts = (QueryConsts*)w->consts.p;
+                p.rot_hi = nullptr; p.rot_lo = nullptr; p.wg_prep = false;
+                HIP_TRY(launch_prep(p, ix->device, st));
             }
             {
                 ProfScope ps(ix, 2, st);
-                hipLaunchKernelGGL(k_probes_given, dim3((uint32_t)n), dim3(kThreads), (size_t)D * 4 + kThreads * 4, st,
-                                   (const uint32_t*)d_lists.p, (const uint32_t*)d_cnts.p, max_lists, (uint32_t)ix->n_lists,
-                                   (int)ix->metric, (const float*)w->rot.p, (const float*)ix->d_centroids, D,
-                                   (const uint32_t*)ix->d_list_gb0, (const uint32_t*)ix->d_list_n, (ProbeInfo*)w->probe.p,
-                                   (StreamItem*)w->wl.p, wl_stride, (uint32_t*)w->nstream.p, (const QueryConsts*)w->consts.p,
-                                   (const BlockSummary*)ix->d_bsum);
-                HIP_TRY(hipGetLastError());
+                ProbesGivenParams p;
+                p.list_ids = (const uint32_t*)d_lists.p; p.list_counts = (const uint32_t*)d_cnts.p; p.max_lists = max_lists;
+                p.nq = (uint32_t)n; p.nlist = (uint32_t)ix->n_lists; p.metric = (int)ix->metric; p.rot = (const float*)w->rot.p;
+                p.cent = (const float*)ix->centroids.p; p.D = D; p.list_gb0 = (const uint32_t*)ix->list_gb0.p;
+                p.list_n = (const uint32_t*)ix->list_n.p; p.probe = (ProbeInfo*)w->probe.p; p.wl = (StreamItem*)w->wl.p;
+                p.wl_stride = wl_stride; p.nstream = (uint32_t*)w->nstream.p; p.consts = (const QueryConsts*)w->consts.p;
+                p.bsum = (const BlockSummary*)ix->bsum.p;
+                HIP_TRY(launch_probes_given(p, st));
             }
-            if ((r2 = scan_stage(ix, w, n, max_lists, top_k, wl_stride, nullptr, 0, (uint64_t*)w->out_ids.p,
-                                 (float*)w->out_scores.p, (uint32_t*)w->out_counts.p, nullptr, /*mstg=*/true, st)))
+            if ((r2 = scan_stage(ix, w, n, max_lists, top_k, wl_stride, nullptr, 0, (uint64_t*)(dp + op.o_ids), (float*)(dp + op.o_scores),
+                                 (uint32_t*)(dp + op.o_counts), nullptr, /*mstg=*/true, st)))
                 return r2;
-            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, w->out_ids.p, n * top_k * 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, w->out_scores.p, n * top_k * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_counts + q0, w->out_counts.p, n * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, dp + op.o_ids, n * top_k * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, dp + op.o_scores, n * top_k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_counts + q0, dp + op.o_counts, n * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
         return RBQ_OK;
@@ -1101,77 +1462,152 @@ int rbq_posting_scan_batch(const rbq_index* cix, const float* queries, uint64_t 
     if (rc) (void)hipStreamSynchronize(w->stream);
     give_ws(ix, w);
     return rc;
+    RBQ_GUARD_END
 }
+
+// ---- optional full-precision rerank (NOT in the reference: its index stores no raw vectors, src/ivf.rs:207-242) ----
+int rbq_index_set_rerank_vectors(rbq_index* h, const float* vectors, uint64_t n) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    if (!h || h->reps.empty()) return fail(RBQ_INVALID_CONFIG, "null index");
+    for (Replica* ix : h->reps) {
+        DeviceGuard g(ix->device);
+        if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+        HIP_TRY(hipDeviceSynchronize());
+        if (ix->raw.p && !ix->raw_borrowed) (void)hipFree(ix->raw.p);
+        ix->raw = Arr(); ix->n_raw = 0; ix->rerank = false; ix->raw_borrowed = false;
+        if (!vectors || n == 0) continue; // detach
+        hipPointerAttribute_t a;
+        const bool on_dev = hipPointerGetAttributes(&a, vectors) == hipSuccess && a.type == hipMemoryTypeDevice;
+        if (!on_dev) (void)hipGetLastError();
+        if (on_dev && a.device == ix->device) { // borrowed: stays owned by the caller, must outlive the index
+            ix->raw.p = const_cast<float*>(vectors); ix->raw.bytes = (size_t)n * ix->dim * 4; ix->raw_borrowed = true;
+        } else {
+            int rc = alloc_arr(ix->raw, (size_t)n * ix->dim * 4);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(ix->raw.p, vectors, (size_t)n * ix->dim * 4, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        }
+        ix->n_raw = n; ix->rerank = true;
+    }
+    return RBQ_OK;
+    RBQ_GUARD_END
+}
+
+// ---- pinned host memory for callers that want zero-copy DMA of queries and results ---------------------
+void* rbq_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void rbq_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---- profiling taps ---------------------------------------------------------------------------------
-void rbq_profile_begin(rbq_index* ix) {
-    if (!ix) return;
-    std::lock_guard<std::mutex> g(ix->mu);
-    for (auto& sp : ix->prof) {
-        for (auto& e : sp.ev) ix->ev_pool.give(e);
-        sp.ev.clear(); sp.ms = 0; sp.launches = 0;
-    }
-    ix->prof_scan_bytes = 0;
-    (void)hipSetDevice(ix->device);
-    (void)hipMemset(ix->d_prof_total, 0, 8);
-    ix->profiling = true;
-}
-void rbq_profile_end(rbq_index* ix) {
-    if (!ix) return;
-    (void)hipSetDevice(ix->device);
-    (void)hipDeviceSynchronize();
-    std::lock_guard<std::mutex> g(ix->mu);
-    ix->profiling = false;
-    {
-        unsigned long long tot = 0;
-        (void)hipMemcpy(&tot, ix->d_prof_total, 8, hipMemcpyDeviceToHost);
-        ix->prof_scan_bytes = tot * (uint64_t)(ix->D / 8 + 12); // sum_q sum_{c in probe(q)} n_c * (D/8 + 12)
-    }
-    for (auto& sp : ix->prof) {
-        for (auto& e : sp.ev) {
-            float ms = 0;
-            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sp.ms += ms; sp.launches++; }
-            ix->ev_pool.give(e);
+void rbq_profile_begin(rbq_index* h) {
+    if (!h) return;
+    for (Replica* ix : h->reps) {
+        DeviceGuard g(ix->device);
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (auto& sp : ix->stage_prof) {
+            for (auto& e : sp.ev) ix->ev_pool.give(e);
+            sp.ev.clear(); sp.ms = 0; sp.launches = 0;
         }
-        sp.ev.clear();
+        for (auto& c : ix->prof_counters) c = 0;
+        (void)hipMemset(ix->prof.p, 0, kProfSlots * 8);
+        ix->profiling = true;
     }
 }
-double rbq_profile_stage_ms(const rbq_index* ix, const char* stage, uint64_t* launches) {
-    if (!ix || !stage) return -1;
+void rbq_profile_end(rbq_index* h) {
+    if (!h) return;
+    for (Replica* ix : h->reps) {
+        DeviceGuard g(ix->device);
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lk(ix->mu);
+        ix->profiling = false;
+        unsigned long long c[kProfSlots] = {0};
+        (void)hipMemcpy(c, ix->prof.p, kProfSlots * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < kProfSlots; ++i) ix->prof_counters[i] = c[i];
+        for (auto& sp : ix->stage_prof) {
+            for (auto& e : sp.ev) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sp.ms += ms; sp.launches++; }
+                ix->ev_pool.give(e);
+            }
+            sp.ev.clear();
+        }
+    }
+}
+double rbq_profile_stage_ms(const rbq_index* h, const char* stage, uint64_t* launches) {
+    if (!h || h->reps.empty() || !stage) return -1;
     int s = !std::strcmp(stage, "prep") ? 0 : !std::strcmp(stage, "rank") ? 1 : !std::strcmp(stage, "select") ? 2 : !std::strcmp(stage, "scan") ? 3 : -1;
     if (s < 0) return -1;
-    if (launches) *launches = ix->prof[s].launches;
-    return ix->prof[s].launches ? ix->prof[s].ms / (double)ix->prof[s].launches : 0.0;
+    double ms = 0; uint64_t n = 0;
+    for (const Replica* ix : h->reps) { ms += ix->stage_prof[s].ms; n += ix->stage_prof[s].launches; }
+    if (launches) *launches = n;
+    return n ? ms / (double)n : 0.0;
 }
-uint64_t rbq_profile_scan_bytes(const rbq_index* ix) { return ix ? ix->prof_scan_bytes : 0; }
-void rbq_profile_select_stages(rbq_index* ix, uint32_t mask) { if (ix) ix->prof_mask = mask & 0xfu; }
-void rbq_profile_set_sampling(rbq_index* ix, uint32_t every) { if (ix) ix->prof_every = every ? every : 1u; }
-int rbq_debug_set_option(rbq_index* ix, const char* name, int value) {
-    if (!ix || !name) return RBQ_INVALID_CONFIG;
-    if (!std::strcmp(name, "block_bound")) { ix->no_block_bound = value == 0; return RBQ_OK; }
-    if (!std::strcmp(name, "exact_rank")) { ix->exact_rank = value != 0; return RBQ_OK; }
-    if (!std::strcmp(name, "exact_heap")) { ix->exact_heap = value != 0; return RBQ_OK; }
-    if (!std::strcmp(name, "f32_rank")) { ix->f32_rank = value != 0; return RBQ_OK; }
-    if (!std::strcmp(name, "wg_prep")) { ix->wg_prep = value != 0; return RBQ_OK; }
-    if (!std::strcmp(name, "small_rank_tiles")) { ix->small_rank_tiles = value != 0; return RBQ_OK; }
-    if (!std::strcmp(name, "force_rank_fallback")) { ix->force_rank_fallback = value != 0; return RBQ_OK; }
-    return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
+uint64_t rbq_profile_scan_bytes(const rbq_index* h) {
+    if (!h || h->reps.empty()) return 0;
+    uint64_t v = 0;
+    for (const Replica* ix : h->reps) v += ix->prof_counters[kProfVectorsProbed];
+    return v * (uint64_t)(h->reps[0]->D / 8 + 12); // sum_q sum_{c in probe(q)} n_c * (D/8 + 12)
 }
-uint64_t rbq_debug_rank_fallbacks(const rbq_index* ix) {
-    if (!ix) return 0;
-    unsigned int v = 0;
-    (void)hipSetDevice(ix->device);
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&v, ix->d_fallbacks, 4, hipMemcpyDeviceToHost);
-    return v;
+int rbq_profile_counters(const rbq_index* h, uint64_t* out, uint32_t n) {
+    if (!h || h->reps.empty() || !out) return RBQ_INVALID_CONFIG;
+    for (uint32_t i = 0; i < n; ++i) {
+        out[i] = 0;
+        if (i < (uint32_t)kProfSlots) for (const Replica* ix : h->reps) out[i] += ix->prof_counters[i];
+    }
+    return RBQ_OK;
 }
+void rbq_profile_select_stages(rbq_index* h, uint32_t mask) { if (h) for (Replica* ix : h->reps) ix->prof_mask = mask & 0xfu; }
+void rbq_profile_set_sampling(rbq_index* h, uint32_t every) { if (h) for (Replica* ix : h->reps) ix->prof_every = every ? every : 1u; }
+
+int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
+    if (!h || h->reps.empty() || !name) return RBQ_INVALID_CONFIG;
+    if (!std::strcmp(name, "debug_replica")) {
+        if (value < 0 || (size_t)value >= h->reps.size()) return fail(RBQ_INVALID_CONFIG, "no such replica");
+        h->debug_replica = value;
+        return RBQ_OK;
+    }
+    for (Replica* ix : h->reps) {
+        if (!std::strcmp(name, "block_bound")) ix->no_block_bound = value == 0;
+        else if (!std::strcmp(name, "exact_rank")) ix->exact_rank = value != 0;
+        else if (!std::strcmp(name, "exact_heap")) ix->exact_heap = value != 0;
+        else if (!std::strcmp(name, "f32_rank")) ix->f32_rank = value != 0;
+        else if (!std::strcmp(name, "wg_prep")) ix->wg_prep = value != 0;
+        else if (!std::strcmp(name, "small_rank_tiles")) ix->small_rank_tiles = value != 0;
+        else if (!std::strcmp(name, "force_rank_fallback")) ix->force_rank_fallback = value != 0;
+        else if (!std::strcmp(name, "rerank")) {
+            if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
+            ix->rerank = value != 0;
+        } else return fail(RBQ_INVALID_CONFIG, std::string("unknown option ") + name);
+    }
+    return RBQ_OK;
+}
+static uint64_t read_counter(const rbq_index* h, int slot) {
+    if (!h) return 0;
+    uint64_t tot = 0;
+    for (const Replica* ix : h->reps) {
+        unsigned int v = 0;
+        DeviceGuard g(ix->device);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(&v, (const unsigned int*)ix->fallbacks.p + slot, 4, hipMemcpyDeviceToHost);
+        tot += v;
+    }
+    return tot;
+}
+uint64_t rbq_debug_rank_fallbacks(const rbq_index* h) { return read_counter(h, 0); }
+uint64_t rbq_debug_heap_restarts(const rbq_index* h) { return read_counter(h, 1); }
 
 /* Diagnostic: copy an intermediate buffer of the workspace bound to `hip_stream` (after the caller synchronised). */
-int rbq_debug_copy_workspace(rbq_index* ix, void* hip_stream, const char* name, void* dst, uint64_t bytes) {
-    if (!ix || !name || !dst) return RBQ_INVALID_CONFIG;
+int rbq_debug_copy_workspace(rbq_index* h, void* hip_stream, const char* name, void* dst, uint64_t bytes) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    if (!h || h->reps.empty() || !name || !dst) return RBQ_INVALID_CONFIG;
+    Replica* ix = h->reps[h->debug_replica];
     Workspace* w = nullptr;
     {
-        std::lock_guard<std::mutex> g(ix->mu);
+        std::lock_guard<std::mutex> lk(ix->mu);
         auto it = ix->stream_ws.find((hipStream_t)hip_stream);
         if (it != ix->stream_ws.end()) w = it->second;
     }
@@ -1186,45 +1622,35 @@ int rbq_debug_copy_workspace(rbq_index* ix, void* hip_stream, const char* name, 
     else if (!std::strcmp(name, "wl")) b = &w->wl;
     else if (!std::strcmp(name, "nvec")) b = &w->nvec;
     if (!b || !b->p || bytes > b->cap) return fail(RBQ_INVALID_CONFIG, "unknown buffer or size");
-    HIP_TRY(hipSetDevice(ix->device));
+    DeviceGuard g(ix->device);
     HIP_TRY(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));
     return RBQ_OK;
-}
-
-int rbq_index_build_device(const rbq_header* hdr, const float* centroids, const float* d_data, const uint32_t* d_assign,
-                           uint64_t n, float t_const, int device, rbq_index** out) {
-    g_err.clear();
-    return build_device_impl(hdr, centroids, d_data, d_assign, n, t_const, device, out);
+    RBQ_GUARD_END
 }
 
 /* Diagnostic: copy one of the index's device arrays to the host. */
-int rbq_debug_copy_index(rbq_index* ix, const char* name, void* dst, uint64_t bytes) {
-    if (!ix || !name || !dst) return RBQ_INVALID_CONFIG;
+int rbq_debug_copy_index(rbq_index* h, const char* name, void* dst, uint64_t bytes) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    if (!h || h->reps.empty() || !name || !dst) return RBQ_INVALID_CONFIG;
+    Replica* ix = h->reps[h->debug_replica];
     const size_t stride = (size_t)ix->Dc * 4 + 384, exd = ex_bytes_dev(ix->D, ix->ex_bits), slots = ix->n_blocks * 32;
     const void* p = nullptr;
     size_t have = 0;
-    if (!std::strcmp(name, "blocks")) { p = ix->d_blocks; have = ix->n_blocks * stride; }
-    else if (!std::strcmp(name, "ids")) { p = ix->d_ids; have = slots * 8; }
-    else if (!std::strcmp(name, "ex")) { p = ix->d_ex; have = slots * exd; }
-    else if (!std::strcmp(name, "fadd_ex")) { p = ix->d_fadd_ex; have = ix->ex_bits ? slots * 4 : 0; }
-    else if (!std::strcmp(name, "fres_ex")) { p = ix->d_fres_ex; have = ix->ex_bits ? slots * 4 : 0; }
-    else if (!std::strcmp(name, "bsum")) { p = ix->d_bsum; have = ix->n_blocks * sizeof(BlockSummary); }
-    else if (!std::strcmp(name, "centroids")) { p = ix->d_centroids; have = ix->n_lists * ix->D * 4; }
-    else if (!std::strcmp(name, "list_gb0")) { p = ix->d_list_gb0; have = ix->n_lists * 4; }
-    else if (!std::strcmp(name, "list_n")) { p = ix->d_list_n; have = ix->n_lists * 4; }
+    if (!std::strcmp(name, "blocks")) { p = ix->blocks.p; have = ix->n_blocks * stride; }
+    else if (!std::strcmp(name, "ids")) { p = ix->ids.p; have = slots * 8; }
+    else if (!std::strcmp(name, "ex")) { p = ix->ex.p; have = slots * exd; }
+    else if (!std::strcmp(name, "fadd_ex")) { p = ix->fadd_ex.p; have = ix->ex_bits ? slots * 4 : 0; }
+    else if (!std::strcmp(name, "fres_ex")) { p = ix->fres_ex.p; have = ix->ex_bits ? slots * 4 : 0; }
+    else if (!std::strcmp(name, "bsum")) { p = ix->bsum.p; have = ix->n_blocks * sizeof(BlockSummary); }
+    else if (!std::strcmp(name, "centroids")) { p = ix->centroids.p; have = ix->n_lists * ix->D * 4; }
+    else if (!std::strcmp(name, "list_gb0")) { p = ix->list_gb0.p; have = ix->n_lists * 4; }
+    else if (!std::strcmp(name, "list_n")) { p = ix->list_n.p; have = ix->n_lists * 4; }
     if (!p || bytes != have) return fail(RBQ_INVALID_CONFIG, "unknown array or size (have " + std::to_string(have) + " bytes)");
-    HIP_TRY(hipSetDevice(ix->device));
+    DeviceGuard g(ix->device);
     HIP_TRY(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
     return RBQ_OK;
-}
-
-uint64_t rbq_debug_heap_restarts(const rbq_index* ix) {
-    if (!ix) return 0;
-    unsigned int v = 0;
-    (void)hipSetDevice(ix->device);
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(&v, (const unsigned int*)ix->d_fallbacks + 1, 4, hipMemcpyDeviceToHost);
-    return v;
+    RBQ_GUARD_END
 }
 
 } // extern "C"

@@ -27,38 +27,8 @@
 
 namespace rbq {
 
-struct ScanParams {
-    const uint8_t* blocks;   // [n_blocks][4Dc + 384]: lane-major sign codes | f_add[32] | f_rescale[32] | f_error[32]
-    const uint64_t* ids;     // [n_blocks*32]
-    const uint8_t* ex_codes; // [n_blocks*32][ex_bytes_dev]: lane-major ex codes, see ex_w4()
-    const float* f_add_ex;   // [n_blocks*32]
-    const float* f_rescale_ex;
-    const uint8_t* lut;      // [nq][4Dc] (pair-swapped codebook order); Dc = D rounded up to x64
-    const float* rot;        // [nq][D]
-    const QueryConsts* consts;
-    const ProbeInfo* probe;  // [nq][nprobe]
-    const StreamItem* wl;    // [nq][wl_stride]
-    const uint32_t* nstream; // [nq]
-    const uint32_t* filter;  // dense bitset or null
-    uint64_t filter_nbits;
-    uint64_t wl_stride;
-    uint64_t* out_ids;
-    float* out_scores;
-    uint32_t* out_counts;
-    unsigned long long* diag; // [nq][3] or null
-    uint32_t D, Dc, nprobe, top_k, metric, ex_bits;
-    uint32_t no_block_bound; // diagnostic: stream every probed block (measures the pure streaming rate)
-    uint32_t exact_heap;     // diagnostic: emulate the reference's BinaryHeap from the start (no sorted fast path)
-    unsigned int* heap_restarts; // counter of queries re-run with the exact heap after a distance tie (or null)
-    uint32_t mstg;           // MSTG posting-list semantics (src/mstg/index.rs:216-330): distance = binary estimate,
-                             // non-finite dropped, L2 clamped to >= 0, no error-bound term
-};
-
 #ifndef RBQ_SCAN_WAVES
 #define RBQ_SCAN_WAVES 5    // launch-bounds occupancy target (waves per SIMD): 96 VGPRs, room for a fifth wave of another kernel
-#endif
-#ifndef RBQ_NSCAN
-#define RBQ_NSCAN 3         // scanner waves per workgroup (3 + replay wave = 256 threads: 4 workgroups per CU)
 #endif
 #ifndef RBQ_LIGHT_MAX
 #define RBQ_LIGHT_MAX 12
@@ -66,27 +36,8 @@ struct ScanParams {
 #ifndef RBQ_PIN_MODE
 #define RBQ_PIN_MODE 1
 #endif
-constexpr int kNScan = RBQ_NSCAN;
-constexpr int kScanThreads = (kNScan + 1) * 64; // scanner waves + 1 replay wave
-constexpr int kTileBlocks = 2 * kNScan;         // 32-vector blocks per tile (one per scanner half-wave)
-constexpr int kTileCand = kTileBlocks * 32;     // candidates per tile
 constexpr uint32_t kLightMax = RBQ_LIGHT_MAX;   // tiles with more survivors than this run synchronously
 constexpr uint32_t kBatchDone = 0xffffffffu;
-
-// Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 units of 16 B, stored [unit][lane][16 B].
-// Lane l holds the codes of dims 16t+l (t = 0..D/16-1); unit j packs codes t = j*CPU .. j*CPU+CPU-1 as a
-// little-endian 128-bit string, ex bits each, with no code straddling two units (CPU = 128/ex: 21 for 6-bit,
-// 64 for 2-bit).  Unused code slots are zero.
-__host__ __device__ constexpr uint32_t ex_cpu(uint32_t ex_bits) { return ex_bits ? 128u / ex_bits : 1u; }
-__host__ __device__ constexpr uint32_t ex_w4(uint32_t D, uint32_t ex_bits) { // 16-byte units per lane
-    return ex_bits ? (D / 16 + ex_cpu(ex_bits) - 1) / ex_cpu(ex_bits) : 0u;
-}
-__host__ __device__ inline uint32_t ex_bytes_dev(uint32_t D, uint32_t ex_bits) { return ex_w4(D, ex_bits) * 256u; }
-// length of the zero-padded rotated query in LDS: every code slot of every unit has a (zero) partner
-__host__ __device__ inline uint32_t ex_qlen(uint32_t D, uint32_t ex_bits) {
-    const uint32_t n = ex_w4(D, ex_bits) * ex_cpu(ex_bits) * 16u;
-    return n > D ? n : D;
-}
 
 // LUT pointer in the LDS address space, formed from a plain integer offset.  A pointer derived from the
 // `extern __shared__` symbol carries a link-time relocation that hipcc adds with one v_add_u32 PER LOOKUP
@@ -431,28 +382,12 @@ struct SortedTop { // operates on the registers of a RegHeap (only one of the tw
     }
 };
 
-// LDS carve-up (dynamic only, LUT at byte 0):
-//   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
-//   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
-//   T, len, nskip, nbatch | batch[kScanThreads/16] u32
-#ifndef RBQ_FILL_K
-#define RBQ_FILL_K 2
-#endif
 #ifndef RBQ_REPLAY_PRIO
 #define RBQ_REPLAY_PRIO 3
 #endif
 #ifndef RBQ_WIN_GROW
 #define RBQ_WIN_GROW 4
 #endif
-constexpr int kFillK = RBQ_FILL_K;                 // stream entries per scanner lane and fill step
-constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
-constexpr int kQueueCap = 512;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
-static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
-__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
-    return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 8;
-}
-
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
 template <int DT, int EX>
 __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParams P) {
@@ -498,7 +433,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
         uint4* dst = reinterpret_cast<uint4*>(s_lut);
         for (uint32_t i = tid; i < Dc / 4; i += kScanThreads) dst[i] = src[i];
         for (uint32_t i = tid; i < qlen; i += kScanThreads) s_q[i] = i < D ? P.rot[(size_t)q * D + i] : 0.0f;
-        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; }
+        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; s_misc[5] = 0; s_misc[6] = 0; }
     }
     // the replay wave is the serial part of every tile: let it issue ahead of the (many) scanner waves it shares
     // its SIMD with
@@ -510,6 +445,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     __syncthreads();
 
     uint32_t n_skip = 0, n_ext = 0, n_est = 0; // n_skip: every thread; n_ext/n_est: replay wave (uniform)
+    // traffic counters of an open profile (P.prof): block records whose codes / factor rows this half-wave
+    // requested, passes over the stream, ex-code evaluations (they survive an exact-heap restart: the traffic is real)
+    uint32_t p_code = 0, p_meta = 0, p_pass = 1, p_ext = 0;
     const bool count_skips = P.diag != nullptr;
 
     // group `g` (16 lanes) refines the survivor at queue position s_batch[g] of tile buffer `buf`.  The ex
@@ -729,6 +667,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             // two memory round trips overlap (the runtime-dimension path keeps the lazy order).
             CodeRegs<DT> cc;
             if (DT && hw < n) load_codes<DT>(cc, blk, l32);
+            if (hw < n) { ++p_meta; if (DT) ++p_code; }
             const Meta m_c = load_meta(wi_c);
             const float T = s_T;
             // per-lane bound with the fresh threshold: the whole wave may be prunable without looking anything up
@@ -747,6 +686,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
 #endif
             if (live_c) { // wave-uniform
                 STAMP(st_a);
+                if (!DT && hw < n) ++p_code;
                 const uint32_t accu = (DT ? lookup_codes<DT>(cc, blk, l32, lut0) : accumulate_block_rt(blk, lut0, l32, Dc)) & 0xffffu;
 #ifdef RBQ_STAMPS
                 asm volatile("" :: "v"(accu));
@@ -1009,6 +949,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     }
     fast = false;
     pos = 0; qhead = 0; qcount = 0; tile = 0; win = (uint32_t)kTileBlocks;
+    p_ext += n_ext; ++p_pass;
     n_skip = 0; n_ext = 0; n_est = 0;
     rh.len = 0;
     __syncthreads();
@@ -1032,7 +973,17 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     }
 
     if (P.diag && n_skip) atomicAdd(s_nskip, n_skip);
+    if (P.prof && scanner && l32 == 0 && p_meta) { atomicAdd(&s_misc[5], p_code); atomicAdd(&s_misc[6], p_meta); }
     __syncthreads();
+    if (P.prof) {
+        if (tid == 0) {
+            atomicAdd(P.prof + kProfCodeBlocks, (unsigned long long)s_misc[5]);
+            atomicAdd(P.prof + kProfMetaBlocks, (unsigned long long)s_misc[6]);
+            atomicAdd(P.prof + kProfStreamEntries, (unsigned long long)ns * p_pass);
+            atomicAdd(P.prof + kProfQueries, 1ull);
+        }
+        if (wave == (uint32_t)kNScan && lane == 0 && ex_bits) atomicAdd(P.prof + kProfExEvals, (unsigned long long)(p_ext + n_ext));
+    }
     const uint32_t len = s_len;
     for (uint32_t i = tid; i < top_k; i += kScanThreads) {
         uint64_t id = ~0ull;

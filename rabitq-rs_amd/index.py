@@ -83,6 +83,26 @@ def lib():
         L.rbq_last_error_detail.restype = C.c_int
         L.rbq_last_error_detail.argtypes = [C.c_char_p, C.c_size_t]
         L.rbq_abi_version.restype = C.c_uint32
+        L.rbq_index_device_count.restype = C.c_uint32
+        L.rbq_index_device_count.argtypes = [vp]
+        L.rbq_build_stream_begin.restype = C.c_int
+        L.rbq_build_stream_begin.argtypes = [vp, vp, vp, C.c_float, C.c_int, C.POINTER(vp)]
+        L.rbq_build_stream_push.restype = C.c_int
+        L.rbq_build_stream_push.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+        L.rbq_build_stream_finish.restype = C.c_int
+        L.rbq_build_stream_finish.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
+        L.rbq_build_stream_abort.restype = None
+        L.rbq_build_stream_abort.argtypes = [vp]
+        L.rbq_release_stream.restype = C.c_int
+        L.rbq_release_stream.argtypes = [vp, vp]
+        L.rbq_host_alloc.restype = vp
+        L.rbq_host_alloc.argtypes = [C.c_size_t]
+        L.rbq_host_free.restype = None
+        L.rbq_host_free.argtypes = [vp]
+        L.rbq_index_set_rerank_vectors.restype = C.c_int
+        L.rbq_index_set_rerank_vectors.argtypes = [vp, vp, C.c_uint64]
+        L.rbq_profile_counters.restype = C.c_int
+        L.rbq_profile_counters.argtypes = [vp, vp, C.c_uint32]
         _LIB = L
     return _LIB
 
@@ -110,12 +130,20 @@ class IvfRabitqIndex:
         self._h = handle
 
     # -- construction -------------------------------------------------------------
+    @staticmethod
+    def _devices(device, devices):
+        """(n_devices, int array | None): `devices` = list of HIP ordinals (one replica each), else `device`."""
+        if devices is not None:
+            devices = list(devices)
+            return len(devices), (C.c_int * len(devices))(*devices)
+        return 1, ((C.c_int * 1)(device) if device is not None else None)
+
     @classmethod
-    def from_built(cls, built, device=None):
+    def from_built(cls, built, device=None, devices=None):
         """Upload a builder.BuiltIndex (ClusterData-shaped host arrays) via rbq_index_create."""
         h = C.c_void_p()
-        dev = (C.c_int * 1)(device) if device is not None else None
-        _check(lib().rbq_index_create(_addr(built.hdr_ptr), _addr(built.lists_ptr), 1, dev, C.byref(h)))
+        n, dev = cls._devices(device, devices)
+        _check(lib().rbq_index_create(_addr(built.hdr_ptr), _addr(built.lists_ptr), n, dev, C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -135,12 +163,12 @@ class IvfRabitqIndex:
         return out
 
     @classmethod
-    def load_from_bytes(cls, data, device=None):
+    def load_from_bytes(cls, data, device=None, devices=None):
         """`load_from_reader` (src/ivf.rs:1484-1702) straight into HBM."""
         h = C.c_void_p()
-        dev = (C.c_int * 1)(device) if device is not None else None
+        n, dev = cls._devices(device, devices)
         buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
-        _check(lib().rbq_index_load_rbq1(buf, len(data), 1, dev, C.byref(h)))
+        _check(lib().rbq_index_load_rbq1(buf, len(data), n, dev, C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -279,6 +307,30 @@ class IvfRabitqIndex:
     def profile_scan_bytes(self):
         return lib().rbq_profile_scan_bytes(self._h)
 
+    def device_count(self):
+        return lib().rbq_index_device_count(self._h)
+
+    def profile_counters(self):
+        """dict of the scan's traffic counters between profile_begin/end (rbq_profile_counters)."""
+        out = (C.c_uint64 * 8)()
+        _check(lib().rbq_profile_counters(self._h, out, 8))
+        names = ("vectors_probed", "code_blocks", "meta_blocks", "stream_entries", "ex_evals", "queries")
+        return {k: int(out[i]) for i, k in enumerate(names)}
+
+    def release_stream(self, stream):
+        _check(lib().rbq_release_stream(self._h, C.c_void_p(stream)))
+
+    def set_rerank_vectors(self, vectors=None, device_ptr=None, n=0):
+        """OPTIONAL extension (default off, not reference behaviour): attach raw vectors for the exact rerank.
+        `vectors` = host array [n][dim], or `device_ptr` + n; None detaches."""
+        if device_ptr is not None:
+            _check(lib().rbq_index_set_rerank_vectors(self._h, C.c_void_p(device_ptr), int(n)))
+        elif vectors is None:
+            _check(lib().rbq_index_set_rerank_vectors(self._h, None, 0))
+        else:
+            v = np.ascontiguousarray(vectors, dtype=np.float32)
+            _check(lib().rbq_index_set_rerank_vectors(self._h, v.ctypes.data, v.shape[0]))
+
     def close(self):
         if self._h:
             lib().rbq_index_destroy(self._h)
@@ -287,5 +339,47 @@ class IvfRabitqIndex:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class StreamBuilder:
+    """Streamed GPU-side encoder (rbq_build_stream_*): `train_with_clusters` (src/ivf.rs:1025-1215) with the
+    vectors delivered chunk by chunk, for data sets that do not fit in HBM at once."""
+
+    def __init__(self, hdr_ptr, centroids, list_sizes, t_const, device=0):
+        cent = np.ascontiguousarray(centroids, dtype=np.float32)
+        ls = np.ascontiguousarray(list_sizes, dtype=np.uint32)
+        self._b = C.c_void_p()
+        _check(lib().rbq_build_stream_begin(_addr(hdr_ptr), cent.ctypes.data, ls.ctypes.data, float(t_const), int(device),
+                                            C.byref(self._b)))
+
+    def push(self, vectors, assign, first_id, count=None):
+        """vectors / assign: numpy arrays (host) or integer device pointers (then `count` is required)."""
+        if isinstance(vectors, np.ndarray):
+            v = np.ascontiguousarray(vectors, dtype=np.float32)
+            a = np.ascontiguousarray(assign, dtype=np.uint32)
+            _check(lib().rbq_build_stream_push(self._b, v.ctypes.data, a.ctypes.data, int(first_id), v.shape[0]))
+        else:
+            _check(lib().rbq_build_stream_push(self._b, C.c_void_p(vectors), C.c_void_p(assign), int(first_id), int(count)))
+
+    def finish(self, devices=None):
+        h = C.c_void_p()
+        if devices is None:
+            _check(lib().rbq_build_stream_finish(self._b, 1, None, C.byref(h)))
+        else:
+            devices = list(devices)
+            _check(lib().rbq_build_stream_finish(self._b, len(devices), (C.c_int * len(devices))(*devices), C.byref(h)))
+        self._b = None
+        return IvfRabitqIndex(h)
+
+    def abort(self):
+        if self._b:
+            lib().rbq_build_stream_abort(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.abort()
         except Exception:
             pass

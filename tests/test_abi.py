@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), f"librbq.so does not export {n}"
-    assert lib.rbq_abi_version() >> 16 == 1
+    assert lib.rbq_abi_version() >> 16 == 2
 
 
 def test_strerror_and_error_codes():
@@ -80,8 +80,9 @@ def test_create_rejects_unsupported_configs_before_touching_the_gpu():
         setattr(bad, field, val)
         rc = ix.lib().rbq_index_create(C.byref(bad), C.cast(built.lists_ptr, C.c_void_p), 1, None, C.byref(h))
         assert rc in (rq._abi.RBQ_INVALID_CONFIG, rq._abi.RBQ_INVALID_PERSISTENCE) and frag in ix._detail(), (field, ix._detail())
-    rc = ix.lib().rbq_index_create(C.byref(hdr), C.cast(built.lists_ptr, C.c_void_p), 2, None, C.byref(h))
-    assert rc == rq._abi.RBQ_INVALID_CONFIG
+    for nd in (0, -1, 17):  # replicas: 1..16 devices
+        rc = ix.lib().rbq_index_create(C.byref(hdr), C.cast(built.lists_ptr, C.c_void_p), nd, None, C.byref(h))
+        assert rc == rq._abi.RBQ_INVALID_CONFIG and "n_devices" in ix._detail()
 
 
 def test_product_package_never_imports_the_oracle():

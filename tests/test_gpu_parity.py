@@ -555,12 +555,14 @@ def test_bench_two_rank_rehearsal():
     env = dict(os.environ, RBQ_BENCH_REHEARSAL="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "4", "--warmup", "1"], env=env, capture_output=True, text=True,
-                         timeout=900)
+                          "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-extras", "--nbatches", "3"], env=env,
+                         capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["streams_identical"] and d["value"] > 0 and d["roofline"]["launches"] == 4
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["pruned"]["launches"] == 4 and d["config"]["distinct_query_batches"] == 3
+    assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["ids_identical_to_product_configuration"]
+    assert 0.0 <= d["pruned"]["block_skip_frac"] < 1.0 and d["recall_at_10"] > 0.9
 
 
 def test_library_first_then_torch_in_a_fresh_process():
