@@ -18,22 +18,32 @@ hipError_t LdsAttrCache::ensure(const void* fn, size_t lds, int device) {
 
 namespace {
 
+template <int DT, int EX, int TR>
+hipError_t launch_scan_r(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    static LdsAttrCache attr;
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_scan<DT, EX, TR>), lds, device);
+    if (e != hipSuccess) return e;
+    if (ev0) hipExtLaunchKernelGGL((k_scan<DT, EX, TR>), dim3(nq), dim3(kScanThreads), lds, s, ev0, ev1, 0, P);
+    else hipLaunchKernelGGL((k_scan<DT, EX, TR>), dim3(nq), dim3(kScanThreads), lds, s, P);
+    return hipGetLastError();
+}
+// top_k <= 64: one register per lane holds the sorted run; 65..kTopKRegMax: four (the reference benchmarks top_k = 100);
+// above that (and for the MSTG scan, which keeps ties in candidate order) the exact heap in LDS, one register
 template <int DT, int EX>
 hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    static LdsAttrCache attr;
-    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_scan<DT, EX>), lds, device);
-    if (e != hipSuccess) return e;
-    if (ev0) hipExtLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, ev0, ev1, 0, P);
-    else hipLaunchKernelGGL((k_scan<DT, EX>), dim3(nq), dim3(kScanThreads), lds, s, P);
-    return hipGetLastError();
+    if (P.top_k > 64u && P.top_k <= kTopKRegMax && !P.exact_heap && !P.mstg) return launch_scan_r<DT, EX, 4>(P, nq, lds, device, s, ev0, ev1);
+    return launch_scan_r<DT, EX, 1>(P, nq, lds, device, s, ev0, ev1);
 }
 template <int DT>
 hipError_t launch_scan_d(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (DT == 0) return launch_scan_t<0, 0>(P, nq, lds, device, s, ev0, ev1);
-    switch (P.ex_bits) {
-        case 0: return launch_scan_t<DT, 0>(P, nq, lds, device, s, ev0, ev1);
-        case 2: return launch_scan_t<DT, 2>(P, nq, lds, device, s, ev0, ev1);
-        default: return launch_scan_t<DT, 6>(P, nq, lds, device, s, ev0, ev1);
+    if constexpr (DT == 0) {
+        return launch_scan_t<0, 0>(P, nq, lds, device, s, ev0, ev1); // runtime dimension and ex_bits
+    } else {
+        switch (P.ex_bits) {
+            case 0: return launch_scan_t<DT, 0>(P, nq, lds, device, s, ev0, ev1);
+            case 2: return launch_scan_t<DT, 2>(P, nq, lds, device, s, ev0, ev1);
+            default: return launch_scan_t<DT, 6>(P, nq, lds, device, s, ev0, ev1);
+        }
     }
 }
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -155,6 +156,7 @@ struct Replica {
     uint64_t n_raw = 0;      // raw vectors attached for the optional rerank
     bool raw_borrowed = false;
     bool rerank = false;
+    uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     // host
@@ -975,26 +977,43 @@ struct OutPack {
     }
 };
 
-// rbq_search_batch on ONE replica: the batch is cut into sub-batches that travel through a few lanes (stream +
-// workspace + pinned staging each).  While lane i runs its kernels, the host stages the next sub-batch into lane
-// i+1's pinned buffer and its H2D copy runs; results come back with one D2H per sub-batch into pinned memory and
-// are handed to the caller's arrays when the lane is needed again (or at the end).  Caller buffers that are already
-// page-locked (rbq_host_alloc / hipHostMalloc / hipHostRegister) are used directly, without staging.
+// rbq_search_batch on ONE replica.  The batch is cut into sub-batches of (by default) 1024 queries that travel through
+// up to four lanes (stream + workspace + pinned staging each), so the stages of neighbouring sub-batches overlap on the
+// GPU exactly like bench.py's device-resident batches do, and the host stages sub-batch j+1 while j runs.
+//  * results: k_scan writes ids / scores / counts / diagnostics STRAIGHT into page-locked host memory (the caller's
+//    buffers when they are page-locked — rbq_host_alloc / hipHostMalloc / hipHostRegister — else the lane's pinned
+//    staging, handed over with one memcpy): 123 KB per 1024 queries, no D2H copy command in the queue;
+//  * queries: page-locked caller buffers are DMA-ed as they are, pageable ones are staged through the lane's pinned
+//    buffer in pieces (the DMA of piece i runs under the memcpy of piece i+1);
+//  * one event per sub-batch, no stream synchronisation.
 int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
                 const uint32_t* filter_words, uint64_t filter_nbits, uint64_t* out_ids, float* out_scores, uint32_t* out_counts,
                 rbq_diag* diag) {
     DeviceGuard g(ix->device);
     if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
-    static const uint32_t env_lanes = [] { const char* e = std::getenv("RBQ_HOST_LANES"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-    static const uint32_t env_sub = [] { const char* e = std::getenv("RBQ_HOST_SUBBATCH"); return e ? (uint32_t)std::atoi(e) : 0u; }();
-    // sub-batch: a quarter of the batch, between 256 and 4096 queries (bounds the nq x nlist score matrix per lane)
-    uint64_t SB = env_sub ? env_sub : std::min<uint64_t>(4096, std::max<uint64_t>(256, align_up((nq + 3) / 4, 64)));
+    using clk = std::chrono::steady_clock;
+    const bool trace = ix->host_trace != 0;
+    double t_attr = 0, t_ws = 0, t_stage = 0, t_enq = 0, t_wait = 0, t_out = 0;
+    auto tick = [&](clk::time_point& t0, double& acc) { if (trace) { const auto t1 = clk::now(); acc += std::chrono::duration<double, std::micro>(t1 - t0).count(); t0 = t1; } };
+    clk::time_point tp = clk::now();
+    uint64_t SB = ix->host_subbatch ? ix->host_subbatch : 1024; // (also bounds the nq x nlist score matrix per lane)
     SB = std::min<uint64_t>(SB, nq);
     const uint64_t nsub = (nq + SB - 1) / SB;
-    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, env_lanes ? env_lanes : 4u);
+    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 4u);
     const bool in_pinned = is_pinned_host_pointer(queries);
-    const bool out_pinned = is_pinned_host_pointer(out_ids) && is_pinned_host_pointer(out_scores) && is_pinned_host_pointer(out_counts) &&
-                            (!diag || is_pinned_host_pointer(diag));
+    bool out_pinned = !ix->rerank && is_pinned_host_pointer(out_ids) && is_pinned_host_pointer(out_scores) &&
+                      is_pinned_host_pointer(out_counts) && (!diag || is_pinned_host_pointer(diag));
+    // device-side addresses of page-locked caller buffers (identical under unified addressing; asked for, not assumed)
+    uint64_t* c_ids = nullptr; float* c_scores = nullptr; uint32_t* c_counts = nullptr; rbq_diag* c_diag = nullptr;
+    if (out_pinned) {
+        if (hipHostGetDevicePointer((void**)&c_ids, out_ids, 0) != hipSuccess || hipHostGetDevicePointer((void**)&c_scores, out_scores, 0) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&c_counts, out_counts, 0) != hipSuccess ||
+            (diag && hipHostGetDevicePointer((void**)&c_diag, diag, 0) != hipSuccess)) {
+            (void)hipGetLastError();
+            out_pinned = false;
+        }
+    }
+    tick(tp, t_attr);
     std::vector<Workspace*> lanes;
     struct Give { Replica* ix; std::vector<Workspace*>& l; bool drained = false;
                   ~Give() { for (Workspace* w : l) { if (!drained) (void)hipStreamSynchronize(w->stream); give_ws(ix, w); } } } give{ix, lanes};
@@ -1003,6 +1022,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         if (!w) return fail(RBQ_DEVICE, "cannot create workspace stream");
         lanes.push_back(w);
     }
+    tick(tp, t_ws);
     int rc;
     const uint32_t* d_filter = nullptr;
     if (filter_words) {
@@ -1014,9 +1034,11 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         for (uint32_t i = 1; i < nlanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i]->stream, w0->done, 0));
         d_filter = (const uint32_t*)w0->filter.p;
     }
-    // hand the finished sub-batch j (in lane's pinned buffer) to the caller's arrays
+    // hand the finished sub-batch j (in the lane's pinned buffer) to the caller's arrays
     auto deliver = [&](Workspace* w, uint64_t j) -> int {
+        clk::time_point td = clk::now();
         HIP_TRY(hipEventSynchronize(w->done));
+        tick(td, t_wait);
         if (out_pinned) return RBQ_OK;
         const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
         const OutPack op(n, top_k, diag != nullptr);
@@ -1025,6 +1047,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         std::memcpy(out_scores + q0 * top_k, src + op.o_scores, n * top_k * 4);
         std::memcpy(out_counts + q0, src + op.o_counts, n * 4);
         if (diag) std::memcpy(diag + q0, src + op.o_diag, n * sizeof(rbq_diag));
+        tick(td, t_out);
         return RBQ_OK;
     };
     for (uint64_t j = 0; j < nsub; ++j) {
@@ -1033,33 +1056,51 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
         const OutPack op(n, top_k, diag != nullptr);
         if ((rc = w->queries.ensure(n * query_dim * 4))) return rc;
-        if ((rc = w->out_pack.ensure(op.total))) return rc;
         const float* src = queries + q0 * query_dim;
-        if (!in_pinned) {
+        tp = clk::now();
+        if (in_pinned) {
+            HIP_TRY(hipMemcpyAsync(w->queries.p, src, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
+        } else {
             if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
-            std::memcpy(w->h_in.p, src, n * query_dim * 4);
-            src = (const float*)w->h_in.p;
+            const uint64_t piece = std::max<uint64_t>(64, (n + 3) / 4); // queries per piece
+            for (uint64_t p0 = 0; p0 < n; p0 += piece) {
+                const size_t off = p0 * query_dim * 4, len = std::min(piece, n - p0) * query_dim * 4;
+                std::memcpy((uint8_t*)w->h_in.p + off, (const uint8_t*)src + off, len);
+                HIP_TRY(hipMemcpyAsync((uint8_t*)w->queries.p + off, (const uint8_t*)w->h_in.p + off, len, hipMemcpyHostToDevice, w->stream));
+            }
         }
-        HIP_TRY(hipMemcpyAsync(w->queries.p, src, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
-        uint8_t* dp = (uint8_t*)w->out_pack.p;
-        rc = search_device(ix, w, (const float*)w->queries.p, n, top_k, nprobe, d_filter, filter_nbits, (uint64_t*)(dp + op.o_ids),
-                           (float*)(dp + op.o_scores), (uint32_t*)(dp + op.o_counts), diag ? (rbq_diag*)(dp + op.o_diag) : nullptr,
+        tick(tp, t_stage);
+        uint64_t* k_ids; float* k_scores; uint32_t* k_counts; rbq_diag* k_diag; // where the kernels write
+        if (out_pinned) {
+            k_ids = c_ids + q0 * top_k; k_scores = c_scores + q0 * top_k; k_counts = c_counts + q0; k_diag = diag ? c_diag + q0 : nullptr;
+        } else if (!ix->rerank) {
+            if ((rc = w->h_out.ensure(op.total))) return rc;
+            uint8_t* hp = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void**)&hp, w->h_out.p, 0));
+            k_ids = (uint64_t*)(hp + op.o_ids); k_scores = (float*)(hp + op.o_scores); k_counts = (uint32_t*)(hp + op.o_counts);
+            k_diag = diag ? (rbq_diag*)(hp + op.o_diag) : nullptr;
+        } else { // the rerank kernel re-reads the ids: keep them in HBM, one D2H copy afterwards
+            if ((rc = w->out_pack.ensure(op.total))) return rc;
+            uint8_t* dp = (uint8_t*)w->out_pack.p;
+            k_ids = (uint64_t*)(dp + op.o_ids); k_scores = (float*)(dp + op.o_scores); k_counts = (uint32_t*)(dp + op.o_counts);
+            k_diag = diag ? (rbq_diag*)(dp + op.o_diag) : nullptr;
+        }
+        rc = search_device(ix, w, (const float*)w->queries.p, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag,
                            w->stream);
         if (rc) return rc;
-        if (out_pinned) {
-            HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, dp + op.o_ids, n * top_k * 8, hipMemcpyDeviceToHost, w->stream));
-            HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, dp + op.o_scores, n * top_k * 4, hipMemcpyDeviceToHost, w->stream));
-            HIP_TRY(hipMemcpyAsync(out_counts + q0, dp + op.o_counts, n * 4, hipMemcpyDeviceToHost, w->stream));
-            if (diag) HIP_TRY(hipMemcpyAsync(diag + q0, dp + op.o_diag, n * sizeof(rbq_diag), hipMemcpyDeviceToHost, w->stream));
-        } else {
+        if (ix->rerank) {
             if ((rc = w->h_out.ensure(op.total))) return rc;
-            HIP_TRY(hipMemcpyAsync(w->h_out.p, dp, op.total, hipMemcpyDeviceToHost, w->stream)); // ONE copy: ids | scores | counts | diag
+            HIP_TRY(hipMemcpyAsync(w->h_out.p, w->out_pack.p, op.total, hipMemcpyDeviceToHost, w->stream));
         }
         HIP_TRY(hipEventRecord(w->done, w->stream));
+        tick(tp, t_enq);
     }
     for (uint64_t j = nsub > nlanes ? nsub - nlanes : 0; j < nsub; ++j)
         if ((rc = deliver(lanes[j % nlanes], j))) return rc;
     give.drained = true; // every lane's last event has been waited for
+    if (trace)
+        std::fprintf(stderr, "[rbq host] nq=%llu sub=%llu lanes=%u pinned(in,out)=%d,%d us: attr %.1f ws %.1f stage %.1f enqueue %.1f wait %.1f copy-out %.1f\n",
+                     (unsigned long long)nq, (unsigned long long)SB, nlanes, (int)in_pinned, (int)out_pinned, t_attr, t_ws, t_stage, t_enq, t_wait, t_out);
     return RBQ_OK;
 }
 
@@ -1577,6 +1618,9 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "wg_prep")) ix->wg_prep = value != 0;
         else if (!std::strcmp(name, "small_rank_tiles")) ix->small_rank_tiles = value != 0;
         else if (!std::strcmp(name, "force_rank_fallback")) ix->force_rank_fallback = value != 0;
+        else if (!std::strcmp(name, "host_lanes")) ix->host_lanes = value > 0 ? (uint32_t)value : 0u;
+        else if (!std::strcmp(name, "host_subbatch")) ix->host_subbatch = value > 0 ? (uint32_t)value : 0u;
+        else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
             ix->rerank = value != 0;

@@ -303,7 +303,7 @@ __device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_a
 // All indices and values are wave-uniform, so every access is a v_readlane/v_writelane (a few cycles)
 // instead of a dependent LDS round trip.
 struct RegHeap {
-    int hd;      // distance bits of entry `lane`
+    int hd;      // distance bits of entry `lane` (also register 0 of the sorted run: only one view is live at a time)
     uint32_t hs; // slot of entry `lane`
     uint32_t len;
     // every index below is wave-uniform; readfirstlane makes that explicit so that hipcc emits a plain
@@ -360,25 +360,68 @@ struct RegHeap {
 // ---- tie-free fast path of the same top-k --------------------------------------------------------------------
 // As long as no two distances in the heap are bit-identical, the reference's result does not depend on the
 // layout of its BinaryHeap: pop evicts THE maximum and into_sorted_vec has one possible order.  The replay wave
-// then keeps the top-k as a sorted run (entry i in lane i, ascending) with one ballot + one DPP shift per
-// insertion instead of a sift-up and a sift-down through v_readlane chains.  An insertion that meets an equal
-// key reports a tie; the query is then re-run from its first block with RegHeap (exact layout emulation).
-struct SortedTop { // operates on the registers of a RegHeap (only one of the two views is live at a time)
-    static __device__ __forceinline__ bool insert(RegHeap& h, int dbits, uint32_t slot, uint32_t top_k) {
-        const uint32_t lane = __lane_id();
-        const int ke = RegHeap::key(dbits), k = RegHeap::key(h.hd);
-        const bool in = lane < h.len;
-        const bool tie = __ballot(in && k == ke) != 0ull;
-        const uint32_t pos = (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
-        const int sd = __builtin_amdgcn_update_dpp(0, h.hd, 0x138, 0xf, 0xf, false);      // wave_shr:1
-        const int ss = __builtin_amdgcn_update_dpp(0, (int)h.hs, 0x138, 0xf, 0xf, false);
-        if (lane == pos) { h.hd = dbits; h.hs = slot; }
-        else if (lane > pos) { h.hd = sd; h.hs = (uint32_t)ss; }
-        h.len = h.len < top_k ? h.len + 1u : h.len; // a full run drops its (new) entry top_k
-        return tie;
+// then keeps the top-k as a SORTED RUN in registers — entry i in lane i % 64 of register i / 64, ascending; TR
+// registers hold up to 64*TR entries (TR = 1: top_k <= 64, TR = 4: top_k <= 256, the reference's own benchmark
+// setting is 100) — with one ballot pair per register and one DPP shift per insertion instead of a sift-up and a
+// sift-down.  An insertion that meets an equal key reports a tie; the query is then re-run from its first block
+// with the exact BinaryHeap emulation (RegHeap for top_k < 64, LdsHeap above).
+// Register 0 of the run is the RegHeap's own pair (d0, s0); registers 1..TR-1 are elements of two vector values
+// (element 0 unused) — vector elements with compile-time indices stay in VGPRs, a plain array ended up in scratch.
+template <int TR>
+struct SortedRun {
+    typedef int VI __attribute__((ext_vector_type(TR)));
+    typedef uint32_t VU __attribute__((ext_vector_type(TR)));
+    // k-th smallest distance (bits) of a run of `len` entries, +inf while the run is not full
+    static __device__ __forceinline__ int kth(int d0, const VI& xd, uint32_t len, uint32_t top_k) {
+        if (len < top_k) return 0x7f800000;
+        const uint32_t kr = (top_k - 1u) >> 6;
+        int v = d0;
+#pragma unroll
+        for (int r = 1; r < TR; ++r) v = kr == (uint32_t)r ? xd[r] : v; // kernel-uniform
+        return __builtin_amdgcn_readlane(v, (int)RegHeap::uni((top_k - 1u) & 63u));
     }
-    static __device__ __forceinline__ float distk(const RegHeap& h, uint32_t top_k) {
-        return h.len < top_k ? INFINITY : __int_as_float(__builtin_amdgcn_readlane(h.hd, (int)RegHeap::uni(top_k - 1u)));
+    // insert (dbits, slot) into the run of `len` entries; returns true if an equal key was met
+    static __device__ __forceinline__ bool insert(int& d0, uint32_t& s0, VI& xd, VU& xs, uint32_t len, int dbits, uint32_t slot,
+                                                  uint32_t lane) {
+        const int ke = RegHeap::key(dbits);
+        uint32_t ipos = 0;
+        bool tie = false;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (TR == 1 || (uint32_t)r * 64u < len) { // uniform: registers above the run hold nothing
+                const int k = RegHeap::key(r == 0 ? d0 : xd[r]);
+                const bool in = (uint32_t)r * 64u + lane < len;
+                tie |= __ballot(in && k == ke) != 0ull;
+                ipos += (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
+            }
+        }
+        const uint32_t rp = ipos >> 6, lp = ipos & 63u;
+        // carries first (register r-1's OLD lane 63 enters register r at lane 0), then every register shifts
+        VI cd = xd;
+        VU cs = xs;
+#pragma unroll
+        for (int r = 1; r < TR; ++r) {
+            cd[r] = __builtin_amdgcn_readlane(r == 1 ? d0 : xd[r - 1], 63);
+            cs[r] = (uint32_t)__builtin_amdgcn_readlane((int)(r == 1 ? s0 : xs[r - 1]), 63);
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int od = r == 0 ? d0 : xd[r];
+            const uint32_t os = r == 0 ? s0 : xs[r];
+            const int sd = __builtin_amdgcn_update_dpp(0, od, 0x138, 0xf, 0xf, false);      // wave_shr:1
+            const int ss = __builtin_amdgcn_update_dpp(0, (int)os, 0x138, 0xf, 0xf, false);
+            int nd = od;
+            uint32_t ns = os;
+            if (r > 0 && (uint32_t)r > rp) { // uniform
+                nd = lane == 0 ? cd[r] : sd;
+                ns = lane == 0 ? cs[r] : (uint32_t)ss;
+            } else if ((uint32_t)r == rp) {
+                nd = lane == lp ? dbits : (lane > lp ? sd : od);
+                ns = lane == lp ? slot : (lane > lp ? (uint32_t)ss : os);
+            }
+            if (r == 0) { d0 = nd; s0 = ns; } else { xd[r] = nd; xs[r] = ns; }
+        }
+        return tie;
     }
 };
 
@@ -389,8 +432,9 @@ struct SortedTop { // operates on the registers of a RegHeap (only one of the tw
 #define RBQ_WIN_GROW 4
 #endif
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
-template <int DT, int EX>
-__global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParams P) {
+// TR: registers of the sorted-run top-k (1: top_k <= 64; 4: top_k <= 256, four waves per SIMD instead of five).
+template <int DT, int EX, int TR>
+__global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smraw[];
     const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
     const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
@@ -567,8 +611,11 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
     uint32_t win = (uint32_t)kTileBlocks;
     // replay-wave state
     const bool reg_heap = top_k < 64;
-    bool fast = reg_heap && !P.exact_heap && !P.mstg; // sorted-run top-k until a distance tie shows up
+    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // sorted-run top-k until a distance tie shows up
+    // the replay wave's top-k registers: RegHeap's pair = register 0 of the sorted run, xd/xs = registers 1..TR-1
     RegHeap rh{0, 0u, 0u};
+    typename SortedRun<TR>::VI xd = 0;
+    typename SortedRun<TR>::VU xs = 0u;
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
@@ -765,7 +812,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
             // replays the examined stretch against the running threshold.
             struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
             auto cur_distk = [&]() -> float {
-                if (fast) return SortedTop::distk(rh, top_k);
+                if (fast) return __int_as_float(SortedRun<TR>::kth(rh.hd, xd, rh.len, top_k));
                 return reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
                                 : (lh.len < top_k ? INFINITY : heap_d[0]);
             };
@@ -804,7 +851,7 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                     // otherwise keeps the state in VGPRs and branches through the exec mask.
                     uint32_t len_s = RegHeap::uni(rh.len);
                     bool tie = false;
-                    int dk = len_s < top_k ? 0x7f800000 : __builtin_amdgcn_readlane(rh.hd, (int)RegHeap::uni(top_k - 1u));
+                    int dk = SortedRun<TR>::kth(rh.hd, xd, len_s, top_k);
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     // The threshold only moves when an entry actually enters the run, so the entries between two
                     // such events are resolved together: one pass of ballots per INSERTION (about a quarter of the
@@ -832,16 +879,9 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
                         const int ke = RegHeap::key(dbits);
                         if (len_s == top_k && ke == RegHeap::key(dk)) { tie = true; continue; } // which of the equal maxima leaves depends on the heap layout
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
-                        const int k = RegHeap::key(rh.hd);
-                        const bool in = lane < len_s;
-                        tie |= __ballot(in && k == ke) != 0ull;
-                        const uint32_t ipos = (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
-                        const int sd = __builtin_amdgcn_update_dpp(0, rh.hd, 0x138, 0xf, 0xf, false);      // wave_shr:1
-                        const int ss = __builtin_amdgcn_update_dpp(0, (int)rh.hs, 0x138, 0xf, 0xf, false);
-                        rh.hd = lane == ipos ? dbits : (lane > ipos ? sd : rh.hd);
-                        rh.hs = lane == ipos ? slot : (lane > ipos ? (uint32_t)ss : rh.hs);
+                        tie |= SortedRun<TR>::insert(rh.hd, rh.hs, xd, xs, len_s, dbits, slot, lane);
                         len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
-                        dk = len_s < top_k ? 0x7f800000 : __builtin_amdgcn_readlane(rh.hd, (int)RegHeap::uni(top_k - 1u));
+                        dk = SortedRun<TR>::kth(rh.hd, xd, len_s, top_k);
                     }
                     rh.len = len_s;
                     n_skip += c_skip; n_ext += c_ext; n_est += c_est;
@@ -956,7 +996,12 @@ __global__ __launch_bounds__(kScanThreads, RBQ_SCAN_WAVES) void k_scan(ScanParam
   }
     if (!scanner) {
         if (fast) { // already sorted ascending
-            if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+                if ((uint32_t)r * 64u + lane < rh.len) {
+                    heap_d[r * 64 + lane] = __int_as_float(r == 0 ? rh.hd : xd[r]);
+                    heap_s[r * 64 + lane] = r == 0 ? rh.hs : xs[r];
+                }
             if (lane == 0) s_len = rh.len;
         } else {
         if (reg_heap) { // spill the register heap to LDS for the final heap-sort
