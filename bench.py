@@ -259,7 +259,7 @@ def main():
         CH = a.stream_build
         nch = (a.n + CH - 1) // CH
         chunk = lambda c: mix.draw(min(CH, a.n - c * CH), 20260105 + c)  # noqa: E731
-        sample = torch.cat([chunk(c)[:max(1, min(CH, 4_000_000 // nch))] for c in range(nch)])
+        sample = torch.cat([chunk(c)[:max(1, min(CH, 4_000_000 // nch))].clone() for c in range(nch)])  # (clone: a slice would pin its whole chunk)
         progress(f"k-means on a {sample.shape[0]}-vector sample")
         cent, _ = kmeans_gpu(torch, sample, a.nlist, a.kmeans_iters, 20260103)
         del sample
@@ -650,21 +650,37 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle  # CPU oracle: checker + reported baseline only
         qh0 = q_all[0].cpu().numpy()
-        cores = oracle.lib().ref_num_threads()
-        t0 = time.perf_counter()
-        rc, oids, osc, ocnt, _ = oracle.search_batch(built, qh0, a.top_k, a.nprobe)  # warm-up pass + parity check
-        pass_t = max(time.perf_counter() - t0, 1e-3)
+        # threads: the box may hand this process fewer CPUs than it shows (cgroup quota / affinity): take the fastest of a
+        # short sweep, so the baseline is the best the host cores given to this job can do
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:
+            mx, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if mx != "max":
+                quota = max(1, int(round(int(mx) / int(per))))
+        except (OSError, ValueError):
+            pass
+        omp_max = oracle.lib().ref_num_threads()
+        cand = sorted({c for c in (quota, 8, 16, 32, 64, avail, omp_max) if c and c <= max(avail, omp_max)})
+        rc, oids, osc, ocnt, _ = oracle.search_batch(built, qh0, a.top_k, a.nprobe, nthreads=cand[0])  # warm-up pass + parity check
+        sweep = {}
+        for c in cand:
+            t0 = time.perf_counter()
+            oracle.search_batch(built, qh0, a.top_k, a.nprobe, nthreads=c)
+            sweep[c] = a.batch / max(time.perf_counter() - t0, 1e-6)
+        cores = max(sweep, key=sweep.get)
+        pass_t = a.batch / sweep[cores]
         same = bool(np.array_equal(oids, ids_all[0]))
         same2 = None
         if NB > 1:  # a second batch of the rotation, so the check is not tied to batch 0
-            rc2, oids2, _, _, _ = oracle.search_batch(built, q_all[NB - 1].cpu().numpy(), a.top_k, a.nprobe)
+            rc2, oids2, _, _, _ = oracle.search_batch(built, q_all[NB - 1].cpu().numpy(), a.top_k, a.nprobe, nthreads=cores)
             same2 = bool(np.array_equal(oids2, ids_all[NB - 1]))
         reps = int(max(1, min(50, round(a.cpu_seconds * 0.6 / 3 / pass_t))))
         rates = []
         for _ in range(3):  # median of 3 timed repeats
             t0 = time.perf_counter()
             for _ in range(reps):
-                oracle.search_batch(built, qh0, a.top_k, a.nprobe)
+                oracle.search_batch(built, qh0, a.top_k, a.nprobe, nthreads=cores)
             rates.append(a.batch * reps / (time.perf_counter() - t0))
         # single thread, sequential queries: how the reference's own benches time it (examples/recall_qps_sweep.rs:127-138)
         ns1 = int(max(8, min(a.batch, 64)))
@@ -678,9 +694,10 @@ def main():
             oracle.search_batch(built, qh0[:ns1], a.top_k, a.nprobe, nthreads=1)
             r1.append(ns1 / (time.perf_counter() - t0))
         out["cpu_baseline"] = {"value": statistics.median(rates), "unit": "queries/s", "cores": cores, "kind": "port",
-                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+                               "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "cpus_in_affinity_mask": avail, "cgroup_cpu_quota": quota,
+                               "thread_sweep_queries_per_s": {str(k): v for k, v in sweep.items()},
                                "sample": f"query batch 0 ({a.batch} queries) on the same index, one query per thread (OpenMP static = "
-                                         f"Rayon par_iter), median of 3 timed repeats of {reps} passes after 1 warm-up pass",
+                                         f"Rayon par_iter) on the fastest thread count of a short sweep, median of 3 timed repeats of {reps} passes after 1 warm-up pass",
                                "all_core_repeats": rates,
                                "single_thread": {"value": statistics.median(r1), "unit": "queries/s", "cores": 1, "repeats": r1,
                                                  "sample": f"first {ns1} queries of batch 0, sequential, median of 3"},
