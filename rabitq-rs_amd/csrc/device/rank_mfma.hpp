@@ -784,6 +784,8 @@ __global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_
 #if RBQ_SEL_STAMPS == 2
         pk = ((ts[0] & 0xffffffffull) << 32) | ((ts[6] - ts[0]) & 0xffffffffull); // absolute start | duration
         nvec_probed[q] = pk;
+#elif RBQ_SEL_STAMPS == 3
+        nvec_probed[q] = s_cnt; // shortlist size
 #else
         for (int t = 0; t < 6; ++t) pk |= (((ts[t + 1] - ts[t]) >> 8) & 0x3ffull) << (10 * t); // 256-cycle units, 10 bits each
         nvec_probed[q] = pk | ((unsigned long long)s_cnt << 60);

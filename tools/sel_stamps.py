@@ -7,20 +7,25 @@ import bench
 import rabitq_rs_amd as rq
 a = bench.parse()
 dev = torch.device("cuda", 0)
-x = bench.mixture(torch, dev, a.n, a.dim, a.nlist, 20260105, False)
+mix = bench.Mixture(torch, dev, a.dim, a.nlist, 'mixture_id32', False)
+x = mix.draw(a.n, 20260105)
 cent, assign = bench.kmeans_gpu(torch, x, a.nlist, 6, 20260103)
 built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits, 0, 1, 20260104, True)
 idx = rq.IvfRabitqIndex.from_built(built)
-qd = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).contiguous()
+qds = [mix.draw(a.batch, 20260102 + i).contiguous() for i in range(3)]
 s = torch.cuda.Stream(dev)
 o = (torch.zeros(a.batch, a.top_k, dtype=torch.int64, device=dev), torch.zeros(a.batch, a.top_k, dtype=torch.float32, device=dev), torch.zeros(a.batch, dtype=torch.int32, device=dev))
-for _ in range(3):
+for qd in qds:
     idx.search_batch_device(qd.data_ptr(), a.batch, a.dim, a.top_k, a.nprobe, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), stream=s.cuda_stream)
 torch.cuda.synchronize(dev)
 v = idx.debug_copy_workspace(s.cuda_stream, "nvec", np.empty(a.batch, np.uint64))
 if os.environ.get("SEL_MODE") == "prep":
     c = idx.debug_copy_workspace(s.cuda_stream, "consts", np.empty(a.batch * 12, np.float32)).reshape(a.batch, 12)
     print("k_prep ticks: rotate %.0f  sums %.0f  lut+consts %.0f" % (c[:, 7].mean(), c[:, 8].mean(), c[:, 9].mean()))
+    sys.exit(0)
+if os.environ.get("SEL_MODE") == "3":
+    c = v.astype(np.int64)
+    print("shortlist size: mean %.1f p50 %d p90 %d p99 %d max %d; > 128: %.1f %%" % (c.mean(), np.percentile(c, 50), np.percentile(c, 90), np.percentile(c, 99), c.max(), 100.0 * (c > 128).mean()))
     sys.exit(0)
 if os.environ.get("SEL_MODE") == "2":
     st = (v >> np.uint64(32)).astype(np.int64); du = (v & np.uint64(0xffffffff)).astype(np.int64)

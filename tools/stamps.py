@@ -7,12 +7,14 @@ import bench
 import rabitq_rs_amd as rq
 a = bench.parse()
 dev = torch.device("cuda", 0)
-x = bench.mixture(torch, dev, a.n, a.dim, a.nlist, 20260105, False)
+mix = bench.Mixture(torch, dev, a.dim, a.nlist, 'mixture_id32', False)
+x = mix.draw(a.n, 20260105)
 cent, assign = bench.kmeans_gpu(torch, x, a.nlist, 6, 20260103)
 built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits, 0, 1, 20260104, True)
 idx = rq.IvfRabitqIndex.from_built(built)
-q = bench.mixture(torch, dev, a.batch, a.dim, a.nlist, 20260102, False).cpu().numpy()
-for _ in range(2):
+qs = [mix.draw(a.batch, 20260102 + i).cpu().numpy() for i in range(3)]
+idx.set_option('host_subbatch', 1 << 20)  # one sub-batch: the diag slots carry the stamps of one launch
+for q in qs:  # the last batch is cold: nothing of it is in the caches
     ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
 d = diag.astype(np.uint64)
 if os.environ.get('RBQ_STAMPS_MODE') == '3':
