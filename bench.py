@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--nbatches", type=int, default=32, help="distinct query batches the steps rotate through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ab", action="store_true", help="kernel A/B runs: only the per-stage pass of the supplementary legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the supplementary legs (second data set, host API, per-stage pass)")
     ap.add_argument("--dataset", default="mixture_id32", choices=["mixture_id32", "isotropic"],
                     help="headline data: low-intrinsic-dimension mixture (default) or SURVEY 8d's isotropic mixture")
@@ -229,7 +230,8 @@ def main():
                                # device encoder produces the identical index (tests/test_gpu_parity.py)
     if a.stream_build:
         a.device_build = True
-    extras = not a.no_extras and rank == 0
+    extras = not a.no_extras and not a.ab and rank == 0
+    stage_pass = (extras or a.ab) and rank == 0
     is_headline = all(getattr(a, k) == v for k, v in HEADLINE.items()) and a.dataset == "mixture_id32"
 
     def progress(msg):
@@ -480,7 +482,7 @@ def main():
                                      "distinct query batch per launch; HIP events carried by the dispatch packets",
                     "note": "traffic (PMC) is collected in separate rocprofv3 passes: profiles/r2/; bytes_requested_per_launch is "
                             "the kernel's own count for the same launches (codes + factor rows + stream + ex codes + LUT)"}
-        if extras:
+        if stage_pass:
             # every stage alone on one stream (no overlap between batches), rotating batches
             stv = torch.cuda.Stream(dev)
             d_i = torch.empty(a.batch, a.top_k, dtype=torch.int64, device=dev)

@@ -6,7 +6,7 @@
 //   k_rank_bf16_db one split-bf16 MFMA GEMM gives APPROXIMATE scores
 //                  A(q,c) = |q|^2 + |c|^2 - 2 q.c   (L2)   or   q.c   (IP)
 //                  with x = hi + lo + r (hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x|) and
-//                  q.c ~ qh.ch + qh.cl + ql.ch on v_mfma_f32_32x32x8_bf16_1k (products exact, f32 accumulate);
+//                  q.c ~ qh.ch + qh.cl + ql.ch on v_mfma_f32_32x32x16_bf16 (products exact, f32 accumulate);
 //                  the dropped terms are <= 3.01 * 2^-16 * sum|q_i||c_i| <= 1.51 * 2^-16 (|q|^2 + |c|^2)
 //   k_rank_mfma    the same scores from one f32 MFMA GEMM (v_mfma_f32_32x32x2_f32), used when D % 64 != 0
 //   k_select_mfma  per query: nprobe-th approximate score tau, shortlist {c : A(c) within 2*eps of tau},
@@ -102,13 +102,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x16 mfma_x8(bf16x8 a, bf16x8 b, f32x16 c) {
+__device__ __forceinline__ f32x16 mfma_x8(bf16x8 a, bf16x8 b, f32x16 c) { // one K = 16 step: c += a(32x16) * b(16x32)
+#ifndef RBQ_MFMA_X8
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); // gfx950's double-rate form
+#else
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 as = __builtin_bit_cast(s16x8, a), bs = __builtin_bit_cast(s16x8, b);
     const s16x4 a0 = {as[0], as[1], as[2], as[3]}, a1 = {as[4], as[5], as[6], as[7]};
     const s16x4 b0 = {bs[0], bs[1], bs[2], bs[3]}, b1 = {bs[4], bs[5], bs[6], bs[7]};
     c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a0, b0, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a1, b1, c, 0, 0, 0);
+#endif
 }
 
 // Split-bf16 GEMM (32*TM*WM x 32*TN*WN tile per workgroup of WM*WN wavefronts, each wavefront a 32*TM x 32*TN
@@ -204,13 +208,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16_db(const uint16_t* _
             BL[b] = *reinterpret_cast<const bf16x8*>(sBh + BN * LDB + rb);                                             \
         }                                                                                                              \
     } while (0)
-    // v_mfma_f32_32x32x16_bf16 (gfx950's double-rate form) is NOT used.  With it in this GEMM, the
-    // workgroup-per-query k_prep of a NEIGHBOURING stream computed wrong LUT bytes (one 16-lane pass
-    // of a quantisation result at a time, tests/diag/stress3.py) although neither kernel writes outside
-    // its own buffers; the K=8 form below never showed it, nor does k_prep_wave with either form,
-    // and a stand-alone MFMA-beside-division test (tools/repro/) stays clean.  Root cause not
-    // established; the combination that ships is the one every stress run has been clean with
-    // (tests/test_gpu_parity.py::test_concurrent_streams_match_oracle guards it).
+    // The MFMA is gfx950's double-rate v_mfma_f32_32x32x16_bf16 (mfma_x8 above).  Round 1 had seen wrong LUT bytes from
+    // the workgroup-per-query k_prep of a NEIGHBOURING stream while an x16 MFMA GEMM ran — in the single-buffered GEMM
+    // kernel of that time, which no longer exists.  With this kernel the combination was re-examined in round 2
+    // (tests/diag/x16_probe.py, x16_tests.py: 3000 rounds of a k_prep victim stream beside three noise streams compared
+    // byte for byte with a quiet run, 12 rounds of the two multi-stream parity tests with k_prep forced): no difference,
+    // so the interaction went with the kernel it was seen in.  test_concurrent_streams_match_oracle (both preparation
+    // kernels) and test_matrix_rotator_concurrent_streams guard the multi-stream path; -DRBQ_MFMA_X8 restores the K=8 form.
 #define RBQ_RANK_MMA(AH, AL, BH, BL)                                                                                   \
     _Pragma("unroll") for (int a = 0; a < TM; ++a) _Pragma("unroll") for (int b = 0; b < TN; ++b) {                    \
         acc[a][b] = mfma_x8(AL[a], BH[b], acc[a][b]);                                                                  \

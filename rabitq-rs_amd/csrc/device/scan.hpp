@@ -428,6 +428,9 @@ struct SortedRun {
 #ifndef RBQ_REPLAY_PRIO
 #define RBQ_REPLAY_PRIO 3
 #endif
+#ifndef RBQ_HEAVY_PER
+#define RBQ_HEAVY_PER 1
+#endif
 #ifndef RBQ_WIN_GROW
 #define RBQ_WIN_GROW 4
 #endif
@@ -529,6 +532,9 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
 
     // small dimensions (one code unit per lane): group `g` of `ng` refines the survivors at queue positions
     // s_batch[g] and s_batch[g + ng] in one pass
+    // heavy tiles: survivors a 16-lane group refines per round when a vector's codes span several units (one after the
+    // other; twice the batch = half the rounds of barrier + collect + replay, at the price of a larger superset)
+    constexpr int kHeavyPer = RBQ_HEAVY_PER;
     constexpr bool kDual = DT != 0 && EX != 0 && ex_w4((uint32_t)(DT ? DT : 16), (uint32_t)(EX ? EX : 2)) == 1u;
     auto refine_pair = [&](uint32_t buf, uint32_t nb, uint32_t g, uint32_t ng) {
         const uint32_t gl = tid & 15u;
@@ -782,7 +788,10 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                     ++st_rounds;
 #endif
                     if (kDual) refine_pair(buf, nb & 0xffffu, tid >> 4, nb >> 16);
-                    else refine_batch(buf, nb & 0xffffu, tid >> 4);
+                    else {
+                        refine_batch(buf, nb & 0xffffu, tid >> 4);
+                        if (kHeavyPer == 2) refine_batch(buf, nb & 0xffffu, (tid >> 4) + (nb >> 16));
+                    }
                     lds_barrier(); // C_r: refined distances visible to the replay wave
                 }
 #ifdef RBQ_STAMPS
@@ -941,13 +950,16 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 // 12 groups refine batch r+1 — collected with the threshold as it stands BEFORE batch r is
                 // replayed, i.e. a superset again — while this wave replays batch r.
                 STAMP(r0);
-                constexpr uint32_t kPer = kDual ? 2u : 1u; // survivors per 16-lane group and round
+                constexpr uint32_t kPer = kDual ? 2u : (uint32_t)kHeavyPer; // survivors per 16-lane group and round
                 Batch cur = collect(0, kPer * (uint32_t)(kScanThreads / 16), cur_distk());
                 RSTAMP(rp_collect);
                 if (lane == 0) s_nbatch = cur.ncol | ((uint32_t)(kScanThreads / 16) << 16); // batch size | groups
                 lds_barrier(); // B_0
                 if (kDual) refine_pair(buf, cur.ncol, tid >> 4, (uint32_t)(kScanThreads / 16));
-                else refine_batch(buf, cur.ncol, tid >> 4);
+                else {
+                    refine_batch(buf, cur.ncol, tid >> 4);
+                    if (kHeavyPer == 2) refine_batch(buf, cur.ncol, (tid >> 4) + (uint32_t)(kScanThreads / 16));
+                }
                 lds_barrier(); // C_0
                 RSTAMP(rp_ref0);
                 while (cur.np < S) {

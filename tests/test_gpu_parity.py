@@ -324,14 +324,17 @@ def test_mstg_posting_scan_rejects_rotated_index():
     idx.close()
 
 
-def test_concurrent_streams_match_oracle():
+@pytest.mark.parametrize("wg_prep", [0, 1])
+def test_concurrent_streams_match_oracle(wg_prep):
     """rbq_search_batch_device on several caller streams at once (bench.py's pipelining): every stream's result
     equals the oracle's.  Kernels of different streams share CUs and SIMDs here, which once exposed a
-    cross-kernel corruption (see rank_mfma.hpp, mfma_x8) that no single-stream test can see."""
+    cross-kernel corruption (see rank_mfma.hpp) that no single-stream test can see; wg_prep=1 forces the
+    workgroup-per-query k_prep, the kernel it had been seen in, beside the x16 bf16 MFMA GEMM."""
     import torch
     dev = torch.device("cuda", 0)
     data, built = build_index(n=60000, dim=960, nlist=256, total_bits=7, seed=23)
     idx = rq.IvfRabitqIndex.from_built(built)
+    idx.set_option("wg_prep", wg_prep)
     nq, top_k, nprobe, ns = 512, 10, 32, 3
     q = make_dataset(nq, 960, 64, 24)
     rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, top_k, nprobe)
