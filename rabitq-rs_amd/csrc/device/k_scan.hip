@@ -27,11 +27,12 @@ hipError_t launch_scan_r(const ScanParams& P, uint32_t nq, size_t lds, int devic
     else hipLaunchKernelGGL((k_scan<DT, EX, TR>), dim3(nq), dim3(kScanThreads), lds, s, P);
     return hipGetLastError();
 }
-// top_k <= 64: one register per lane holds the sorted run; 65..kTopKRegMax: four (the reference benchmarks top_k = 100);
-// above that (and for the MSTG scan, which keeps ties in candidate order) the exact heap in LDS, one register
+// top_k <= 63: one register per lane of the replay wave holds the top-k (bag, or the exact heap after a distance tie);
+// 64..128: two registers (the reference benchmarks top_k = 100); ..kTopKRegMax = 256: four; above that the exact heap in LDS
 template <int DT, int EX>
 hipError_t launch_scan_t(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (P.top_k > 64u && P.top_k <= kTopKRegMax && !P.exact_heap && !P.mstg) return launch_scan_r<DT, EX, 4>(P, nq, lds, device, s, ev0, ev1);
+    if (P.top_k >= 64u && P.top_k <= 128u) return launch_scan_r<DT, EX, 2>(P, nq, lds, device, s, ev0, ev1);
+    if (P.top_k > 128u && P.top_k <= kTopKRegMax) return launch_scan_r<DT, EX, 4>(P, nq, lds, device, s, ev0, ev1);
     return launch_scan_r<DT, EX, 1>(P, nq, lds, device, s, ev0, ev1);
 }
 template <int DT>

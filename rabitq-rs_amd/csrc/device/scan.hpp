@@ -299,24 +299,55 @@ __device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_a
     return sacc;
 }
 
-// ---- the same BinaryHeap held in the replay wave's registers: entry i lives in lane i (top_k <= 63) --------
+// ---- the same BinaryHeap held in the replay wave's registers ------------------------------------------------
+// Entry i lives in lane i % 64 of register i / 64; TR registers hold 64*TR entries (the heap is one entry over top_k
+// between a push and the pop that follows, so top_k <= 64*TR - 1: 63 with one register, 255 with four).
 // All indices and values are wave-uniform, so every access is a v_readlane/v_writelane (a few cycles)
-// instead of a dependent LDS round trip.
-struct RegHeap {
-    int hd;      // distance bits of entry `lane` (also register 0 of the sorted run: only one view is live at a time)
-    uint32_t hs; // slot of entry `lane`
-    uint32_t len;
-    // every index below is wave-uniform; readfirstlane makes that explicit so that hipcc emits a plain
-    // v_readlane instead of a waterfall loop
+// instead of a dependent LDS round trip.  Register 0 is the pair (hd, hs); registers 1..TR-1 are elements of two
+// vector values (element 0 unused) — vector elements with compile-time indices stay in VGPRs, a plain array ended up
+// in scratch.  The sorted run (SortedRun below) is a second view of the same registers; only one is live at a time.
+struct HeapOps {
+    // every index is wave-uniform; readfirstlane makes that explicit so that hipcc emits a plain v_readlane instead of
+    // a waterfall loop
     static __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-    __device__ __forceinline__ int d_at(uint32_t i) const { return __builtin_amdgcn_readlane(hd, (int)uni(i)); }
-    __device__ __forceinline__ uint32_t s_at(uint32_t i) const { return (uint32_t)__builtin_amdgcn_readlane((int)hs, (int)uni(i)); }
-    __device__ __forceinline__ void set(uint32_t i, int d, uint32_t s) { // v_writelane as compare+select
-        const bool me = (__lane_id() == uni(i));
-        hd = me ? d : hd;
-        hs = me ? s : hs;
-    }
     static __device__ __forceinline__ int key(int bits) { return bits ^ (int)(((uint32_t)(bits >> 31)) >> 1); }
+};
+template <int TR>
+struct RegHeap : HeapOps {
+    typedef int VI __attribute__((ext_vector_type(TR)));
+    typedef uint32_t VU __attribute__((ext_vector_type(TR)));
+    int hd;      // distance bits of entry `lane`
+    uint32_t hs; // slot of entry `lane`
+    VI xd;       // entries 64r + lane, r = 1..TR-1
+    VU xs;
+    uint32_t len;
+    __device__ __forceinline__ int d_at(uint32_t i) const {
+        const uint32_t r = uni(i >> 6);
+        int v = hd;
+#pragma unroll
+        for (int k = 1; k < TR; ++k) v = r == (uint32_t)k ? xd[k] : v;
+        return __builtin_amdgcn_readlane(v, (int)uni(i & 63u));
+    }
+    __device__ __forceinline__ uint32_t s_at(uint32_t i) const {
+        const uint32_t r = uni(i >> 6);
+        uint32_t v = hs;
+#pragma unroll
+        for (int k = 1; k < TR; ++k) v = r == (uint32_t)k ? xs[k] : v;
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uni(i & 63u));
+    }
+    __device__ __forceinline__ void set(uint32_t i, int d, uint32_t s) { // v_writelane as compare+select
+        const uint32_t r = uni(i >> 6);
+        const bool me = (__lane_id() == uni(i & 63u));
+        const bool m0 = me && r == 0u;
+        hd = m0 ? d : hd;
+        hs = m0 ? s : hs;
+#pragma unroll
+        for (int k = 1; k < TR; ++k) {
+            const bool mk = me && r == (uint32_t)k;
+            xd[k] = mk ? d : xd[k];
+            xs[k] = mk ? s : xs[k];
+        }
+    }
     __device__ __forceinline__ void sift_up(uint32_t pos, int ed, uint32_t es) {
         const int ke = key(ed);
         pos = uni(pos);
@@ -360,13 +391,66 @@ struct RegHeap {
 // ---- tie-free fast path of the same top-k --------------------------------------------------------------------
 // As long as no two distances in the heap are bit-identical, the reference's result does not depend on the
 // layout of its BinaryHeap: pop evicts THE maximum and into_sorted_vec has one possible order.  The replay wave
-// then keeps the top-k as a SORTED RUN in registers — entry i in lane i % 64 of register i / 64, ascending; TR
-// registers hold up to 64*TR entries (TR = 1: top_k <= 64, TR = 4: top_k <= 256, the reference's own benchmark
-// setting is 100) — with one ballot pair per register and one DPP shift per insertion instead of a sift-up and a
-// sift-down.  An insertion that meets an equal key reports a tie; the query is then re-run from its first block
-// with the exact BinaryHeap emulation (RegHeap for top_k < 64, LdsHeap above).
-// Register 0 of the run is the RegHeap's own pair (d0, s0); registers 1..TR-1 are elements of two vector values
-// (element 0 unused) — vector elements with compile-time indices stay in VGPRs, a plain array ended up in scratch.
+// then keeps the top-k as an UNORDERED BAG in the RegHeap's registers (entry i in lane i % 64 of register i / 64,
+// TR registers = up to 64*TR entries; the reference's own benchmark setting is top_k = 100) together with the bits of
+// its maximum: an insertion into a full bag overwrites the maximum's slot and recomputes the maximum with one DPP
+// wave reduction — no position search, no shifting — and the bag is sorted once, when the query is finished.  (A sorted
+// run with one shift per insertion was the first form; at top_k = 100 the replay wave, a single wave per query,
+// spent 2/3 of the kernel's time in it.)  An insertion that meets an equal key reports a tie; the query is then
+// re-run from its first block with the exact BinaryHeap emulation (RegHeap while top_k < 64*TR, LdsHeap above).
+template <int TR>
+struct BagTop {
+    typedef RegHeap<TR> H;
+    // bits of the largest distance among the first `len` entries (the bag's k-th smallest once it is full)
+    static __device__ __forceinline__ int max_bits(const H& h, uint32_t len, uint32_t lane) {
+        int m = (int)0x80000000;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (TR == 1 || (uint32_t)r * 64u < len) { // uniform: registers above the bag hold nothing
+                const int k = HeapOps::key(r == 0 ? h.hd : h.xd[r]);
+                m = ((uint32_t)r * 64u + lane < len && k > m) ? k : m;
+            }
+        }
+        // wave maximum: Hillis-Steele inside each row of 16 lanes, then row 0/2 -> 1/3, then lane 31 -> rows 2,3
+        const int lo = (int)0x80000000;
+        int t;
+        t = __builtin_amdgcn_update_dpp(lo, m, 0x111, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(lo, m, 0x112, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(lo, m, 0x114, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(lo, m, 0x118, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(lo, m, 0x142, 0xa, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(lo, m, 0x143, 0xc, 0xf, false); m = t > m ? t : m;
+        return HeapOps::key(__builtin_amdgcn_readlane(m, 63)); // key() is its own inverse
+    }
+    // Insert (dbits, slot) into a bag of `len` entries whose maximum has the bits `dk` (valid when len == top_k; the new
+    // key is then smaller).  Updates len and dk; returns true if an equal key was met.
+    static __device__ __forceinline__ bool insert(H& h, uint32_t& len, int& dk, uint32_t top_k, int dbits, uint32_t slot, uint32_t lane) {
+        const int ke = HeapOps::key(dbits), kmax = HeapOps::key(dk);
+        const bool full = len == top_k;
+        bool tie = false;
+        uint32_t pos = len; // append while the bag is filling
+        bool found = false;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (TR == 1 || (uint32_t)r * 64u < len) {
+                const int k = HeapOps::key(r == 0 ? h.hd : h.xd[r]);
+                const bool in = (uint32_t)r * 64u + lane < len;
+                tie |= __ballot(in && k == ke) != 0ull;
+                if (full && !found) { // uniform: the slot of the maximum (unique: a tie at the maximum restarts the query)
+                    const unsigned long long mm = __ballot(in && k == kmax);
+                    if (mm) { pos = (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(mm); found = true; }
+                }
+            }
+        }
+        h.set(pos, dbits, slot);
+        len = full ? len : len + 1u;
+        if (len == top_k) dk = max_bits(h, len, lane);
+        return tie;
+    }
+};
+
+// One register per lane (top_k <= 64): a SORTED RUN, entry i in lane i — one ballot pair and one DPP shift per
+// insertion, the k-th distance is a readlane.  (With several registers the bag above is cheaper.)
 template <int TR>
 struct SortedRun {
     typedef int VI __attribute__((ext_vector_type(TR)));
@@ -378,18 +462,18 @@ struct SortedRun {
         int v = d0;
 #pragma unroll
         for (int r = 1; r < TR; ++r) v = kr == (uint32_t)r ? xd[r] : v; // kernel-uniform
-        return __builtin_amdgcn_readlane(v, (int)RegHeap::uni((top_k - 1u) & 63u));
+        return __builtin_amdgcn_readlane(v, (int)HeapOps::uni((top_k - 1u) & 63u));
     }
     // insert (dbits, slot) into the run of `len` entries; returns true if an equal key was met
     static __device__ __forceinline__ bool insert(int& d0, uint32_t& s0, VI& xd, VU& xs, uint32_t len, int dbits, uint32_t slot,
                                                   uint32_t lane) {
-        const int ke = RegHeap::key(dbits);
+        const int ke = HeapOps::key(dbits);
         uint32_t ipos = 0;
         bool tie = false;
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             if (TR == 1 || (uint32_t)r * 64u < len) { // uniform: registers above the run hold nothing
-                const int k = RegHeap::key(r == 0 ? d0 : xd[r]);
+                const int k = HeapOps::key(r == 0 ? d0 : xd[r]);
                 const bool in = (uint32_t)r * 64u + lane < len;
                 tie |= __ballot(in && k == ke) != 0ull;
                 ipos += (uint32_t)__popcll(__ballot(in && k < ke)); // sorted: the smaller keys are a prefix
@@ -435,7 +519,8 @@ struct SortedRun {
 #define RBQ_WIN_GROW 4
 #endif
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
-// TR: registers of the sorted-run top-k (1: top_k <= 64; 4: top_k <= 256, four waves per SIMD instead of five).
+// TR: registers per lane of the replay wave's top-k (1: top_k <= 63; 2: <= 128; 4: <= 256 — with more than one,
+// four waves per SIMD instead of five).
 template <int DT, int EX, int TR>
 __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smraw[];
@@ -616,12 +701,11 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     // (x RBQ_WIN_GROW per step, up to kFillK entries per scanner lane).
     uint32_t win = (uint32_t)kTileBlocks;
     // replay-wave state
-    const bool reg_heap = top_k < 64;
-    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // sorted-run top-k until a distance tie shows up
-    // the replay wave's top-k registers: RegHeap's pair = register 0 of the sorted run, xd/xs = registers 1..TR-1
-    RegHeap rh{0, 0u, 0u};
-    typename SortedRun<TR>::VI xd = 0;
-    typename SortedRun<TR>::VU xs = 0u;
+    const bool reg_heap = top_k < 64u * TR;                     // exact BinaryHeap emulation in registers (else in LDS)
+    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // bag top-k (BagTop) until a distance tie shows up
+    RegHeap<TR> rh; // the replay wave's top-k registers: exact heap, or (same registers) the bag
+    rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
+    int bag_dk = 0x7f800000; // bits of the bag's maximum (valid once it holds top_k entries)
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
@@ -821,7 +905,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             // replays the examined stretch against the running threshold.
             struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
             auto cur_distk = [&]() -> float {
-                if (fast) return __int_as_float(SortedRun<TR>::kth(rh.hd, xd, rh.len, top_k));
+                if (fast) return rh.len < top_k ? INFINITY : __int_as_float(TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, rh.len, top_k) : bag_dk);
                 return reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
                                 : (lh.len < top_k ? INFINITY : heap_d[0]);
             };
@@ -858,22 +942,22 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 if (fast) {
                     // Everything here is wave-uniform; ballots and readfirstlane say so to the compiler, which
                     // otherwise keeps the state in VGPRs and branches through the exec mask.
-                    uint32_t len_s = RegHeap::uni(rh.len);
+                    uint32_t len_s = HeapOps::uni(rh.len);
                     bool tie = false;
-                    int dk = SortedRun<TR>::kth(rh.hd, xd, len_s, top_k);
+                    int dk = TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k) : (len_s < top_k ? 0x7f800000 : (int)HeapOps::uni((uint32_t)bag_dk));
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     // The threshold only moves when an entry actually enters the run, so the entries between two
                     // such events are resolved together: one pass of ballots per INSERTION (about a quarter of the
                     // evaluated survivors), not per survivor.  Lane j holds taken survivor j of the stretch.
                     const float lbv = __int_as_float(bt.v_lb), dvf = __int_as_float(v_d);
                     const bool fin_l = (v_d & 0x7f800000) != 0x7f800000;
-                    const int kd_l = RegHeap::key(v_d);
+                    const int kd_l = HeapOps::key(v_d);
                     const unsigned long long fin_m = __ballot(fin_l);
                     (void)dvf;
                     while (todo) {
                         const unsigned long long cand = __ballot(lbv < __int_as_float(dk)) & todo; // evaluated by the reference
                         // entries that change the run (or tie with its maximum): finite and not beyond the k-th
-                        const bool chg = fin_l && (len_s < top_k || kd_l <= RegHeap::key(dk));
+                        const bool chg = fin_l && (len_s < top_k || kd_l <= HeapOps::key(dk));
                         const unsigned long long ins = __ballot(chg) & cand;
                         const unsigned long long before = ins ? ((1ull << __builtin_ctzll(ins)) - 1ull) : ~0ull;
                         const unsigned long long done = todo & before; // resolved without a change of state
@@ -885,14 +969,19 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                         todo &= ~((2ull << j) - 1ull);
                         ++c_ext; ++c_est;
                         const int dbits = __builtin_amdgcn_readlane(v_d, (int)j);
-                        const int ke = RegHeap::key(dbits);
-                        if (len_s == top_k && ke == RegHeap::key(dk)) { tie = true; continue; } // which of the equal maxima leaves depends on the heap layout
+                        const int ke = HeapOps::key(dbits);
+                        if (len_s == top_k && ke == HeapOps::key(dk)) { tie = true; continue; } // which of the equal maxima leaves depends on the heap layout
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
-                        tie |= SortedRun<TR>::insert(rh.hd, rh.hs, xd, xs, len_s, dbits, slot, lane);
-                        len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
-                        dk = SortedRun<TR>::kth(rh.hd, xd, len_s, top_k);
+                        if (TR == 1) {
+                            tie |= SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane);
+                            len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
+                            dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
+                        } else {
+                            tie |= BagTop<TR>::insert(rh, len_s, dk, top_k, dbits, slot, lane); // (dk stays +inf while filling)
+                        }
                     }
                     rh.len = len_s;
+                    bag_dk = dk;
                     n_skip += c_skip; n_ext += c_ext; n_est += c_est;
                     if (tie && lane == 0) s_restart = 1u;
                 } else if (reg_heap) {
@@ -1004,20 +1093,41 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     p_ext += n_ext; ++p_pass;
     n_skip = 0; n_ext = 0; n_est = 0;
     rh.len = 0;
+    bag_dk = 0x7f800000;
     __syncthreads();
   }
     if (!scanner) {
-        if (fast) { // already sorted ascending
+        if (fast && TR == 1) { // the sorted run: already ascending
+            if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
+            if (lane == 0) s_len = rh.len;
+        } else if (fast) {
+            // sort the bag once: keys to LDS (a tile buffer is free by now), rank of every entry by counting the smaller
+            // keys (distinct: no tie was met), entries to their rank
+            int* s_key = reinterpret_cast<int*>(q_d); // [<= 64*TR <= 2*kTileCand]
+            const uint32_t blen = rh.len;
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+                if ((uint32_t)r * 64u + lane < blen) s_key[r * 64 + lane] = HeapOps::key(r == 0 ? rh.hd : rh.xd[r]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                if (TR == 1 || (uint32_t)r * 64u < blen) {
+                    const int dv = r == 0 ? rh.hd : rh.xd[r];
+                    const int my = HeapOps::key(dv);
+                    uint32_t rank = 0;
+                    for (uint32_t j = 0; j < blen; ++j) rank += s_key[j] < my ? 1u : 0u;
+                    if ((uint32_t)r * 64u + lane < blen) { heap_d[rank] = __int_as_float(dv); heap_s[rank] = r == 0 ? rh.hs : rh.xs[r]; }
+                }
+            }
+            if (lane == 0) s_len = blen;
+        } else {
+        if (reg_heap) { // spill the register heap to LDS for the final heap-sort
 #pragma unroll
             for (int r = 0; r < TR; ++r)
                 if ((uint32_t)r * 64u + lane < rh.len) {
-                    heap_d[r * 64 + lane] = __int_as_float(r == 0 ? rh.hd : xd[r]);
-                    heap_s[r * 64 + lane] = r == 0 ? rh.hs : xs[r];
+                    heap_d[r * 64 + lane] = __int_as_float(r == 0 ? rh.hd : rh.xd[r]);
+                    heap_s[r * 64 + lane] = r == 0 ? rh.hs : rh.xs[r];
                 }
-            if (lane == 0) s_len = rh.len;
-        } else {
-        if (reg_heap) { // spill the register heap to LDS for the final heap-sort
-            if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
             lh.len = rh.len;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

@@ -105,7 +105,7 @@ constexpr int kFillK = RBQ_FILL_K;                 // stream entries per scanner
 constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
 constexpr int kQueueCap = 512;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
-constexpr uint32_t kTopKRegMax = 256;             // largest top_k whose sorted run lives in the replay wave's registers
+constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
 
 // Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 units of 16 B, stored [unit][lane][16 B].
 // Lane l holds the codes of dims 16t+l (t = 0..D/16-1); unit j packs codes t = j*CPU .. j*CPU+CPU-1 as a
