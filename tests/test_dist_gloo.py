@@ -1,7 +1,9 @@
 """world_size-2 rehearsal of the multi-GPU path on CPU (gloo): queries are sharded across ranks with the
-index replicated; the only exchange is the all_gather of per-rank [batch][top_k] (id, score) blocks
-(SURVEY.md §8e).  The per-rank search is played by the oracle here (no GPU in this container) — what is under
-test is the sharding/gather logic bench.py uses: order preservation and equality with the unsharded result."""
+index replicated; the only exchange is the all_gather of per-rank packed [batch][top_k] (id, score) blocks
+(SURVEY.md §8e).  The per-rank search is played by the oracle here (no GPU in this container); the packing, the
+gather and the unpacking are bench.py's own code (bench.TopkExchange — the object the timed loop uses on HBM buffers
+over RCCL): order preservation and bit-equality with the unsharded result, with two batches in flight on two
+exchange slots."""
 import os
 import socket
 import sys
@@ -23,21 +25,27 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
     import oracle
     from conftest import build_index, make_dataset
     data, built = build_index(n=1500, dim=64, nlist=12, total_bits=7, seed=77)   # replicated: same seed on every rank
-    q_all = make_dataset(32, 64, 3, 123)
-    per = q_all.shape[0] // world
-    q = q_all[rank * per:(rank + 1) * per]                                          # contiguous query shard
-    rc, ids, sc, cnt, _ = oracle.search_batch(built, q, 10, 6)
-    t_ids = torch.from_numpy(ids.view(np.int64).copy()); t_sc = torch.from_numpy(sc.copy())
-    g_ids = [torch.empty_like(t_ids) for _ in range(world)]; g_sc = [torch.empty_like(t_sc) for _ in range(world)]
-    dist.all_gather(g_ids, t_ids); dist.all_gather(g_sc, t_sc)                      # the path's only collective
+    top_k, nprobe, batch = 10, 6, 16
+    ex = bench.TopkExchange(torch, torch.device("cpu"), batch, top_k, 2, world, gather=True)
+    ok = True
+    for slot, seed in ((0, 123), (1, 124)):                                          # two batches, two exchange slots
+        q_all = make_dataset(batch * world, 64, 3, seed)
+        q = q_all[rank * batch:(rank + 1) * batch]                                   # contiguous query shard
+        rc, ids, sc, cnt, _ = oracle.search_batch(built, q, top_k, nprobe)
+        ex.ids[slot].copy_(torch.from_numpy(ids.view(np.int64).copy()))            # what rbq_search_batch_device writes
+        ex.scores[slot].copy_(torch.from_numpy(sc.copy()))
+        ex.gather(dist, slot)                                                        # the path's only collective
     dist.barrier()
     if rank == 0:
-        full_ids = torch.cat(g_ids).numpy().view(np.uint64); full_sc = torch.cat(g_sc).numpy()
-        rc, rids, rsc, rcnt, _ = oracle.search_batch(built, q_all, 10, 6)
-        ok = np.array_equal(full_ids, rids) and np.array_equal(full_sc.view(np.uint32), rsc.view(np.uint32))
+        for slot, seed in ((0, 123), (1, 124)):
+            q_all = make_dataset(batch * world, 64, 3, seed)
+            gid, gsc = ex.unpack(slot)
+            rc, rids, rsc, rcnt, _ = oracle.search_batch(built, q_all, top_k, nprobe)
+            ok &= np.array_equal(gid.numpy().view(np.uint64), rids) and np.array_equal(gsc.numpy().view(np.uint32), rsc.view(np.uint32))
         open(os.path.join(out_dir, "ok"), "w").write("1" if ok else "0")
     dist.destroy_process_group()
 
