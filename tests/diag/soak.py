@@ -37,7 +37,7 @@ def wide_case(seed):
     nmax = max(nlist + 1, min(30000, 6_000_000 // dim))
     n = int(rng.integers(nlist, nmax))
     nq = int(rng.integers(1, 64))
-    top_k = int(rng.choice([1, 2, 5, 10, 17, 63, 64, 65, 100, 300]))
+    top_k = int(rng.choice([1, 2, 5, 10, 17, 63, 64, 65, 100, 128, 129, 200, 255, 256, 257, 300]))  # register top-k: 1 / 2 / 4 per lane, LDS above 256
     nprobe = int(rng.integers(1, nlist + 3))
     filt = float(rng.choice([0.0, 0.0, 0.0, 0.01, 0.1, 0.5, 0.9]))
     short = bool(rng.integers(0, 2))
@@ -75,7 +75,7 @@ def ties_case(seed):
     nlist = int(rng.integers(2, 40))
     n = int(rng.integers(max(200, nlist * 4), 6000))
     return dict(dim=dim, nlist=nlist, n=n, distinct=int(rng.integers(3, max(4, n // 8))), bits=int(rng.choice([1, 3, 7])),
-                metric=int(rng.integers(0, 2)), nq=int(rng.integers(1, 40)), top_k=int(rng.choice([1, 2, 5, 10, 17, 63, 64, 100])),
+                metric=int(rng.integers(0, 2)), nq=int(rng.integers(1, 40)), top_k=int(rng.choice([1, 2, 5, 10, 17, 63, 64, 100, 128, 129, 255, 256, 300])),
                 nprobe=int(rng.integers(1, nlist + 1)), from_data=bool(rng.integers(0, 2)))
 
 
