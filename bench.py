@@ -74,7 +74,7 @@ def parse():
                          "(indexes whose raw vectors exceed HBM: cfg5)")
     ap.add_argument("--kmeans-iters", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], help="rbq_debug_set_option name=value (diagnostic A/B runs)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the batches are issued on, round-robin")
+    ap.add_argument("--streams", type=int, default=6, help="HIP streams the batches are issued on, round-robin (tools/streams_sweep.py)")
     return ap.parse_args()
 
 
