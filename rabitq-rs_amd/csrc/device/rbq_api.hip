@@ -978,7 +978,7 @@ struct OutPack {
 };
 
 // rbq_search_batch on ONE replica.  The batch is cut into sub-batches of (by default) 1024 queries that travel through
-// up to four lanes (stream + workspace + pinned staging each), so the stages of neighbouring sub-batches overlap on the
+// up to six lanes (stream + workspace + pinned staging each), so the stages of neighbouring sub-batches overlap on the
 // GPU exactly like bench.py's device-resident batches do, and the host stages sub-batch j+1 while j runs.
 //  * results: k_scan writes ids / scores / counts / diagnostics STRAIGHT into page-locked host memory (the caller's
 //    buffers when they are page-locked — rbq_host_alloc / hipHostMalloc / hipHostRegister — else the lane's pinned
@@ -999,7 +999,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     uint64_t SB = ix->host_subbatch ? ix->host_subbatch : 1024; // (also bounds the nq x nlist score matrix per lane)
     SB = std::min<uint64_t>(SB, nq);
     const uint64_t nsub = (nq + SB - 1) / SB;
-    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 4u);
+    const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 6u);
     const bool in_pinned = is_pinned_host_pointer(queries);
     bool out_pinned = !ix->rerank && is_pinned_host_pointer(out_ids) && is_pinned_host_pointer(out_scores) &&
                       is_pinned_host_pointer(out_counts) && (!diag || is_pinned_host_pointer(diag));
