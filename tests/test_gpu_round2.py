@@ -409,3 +409,79 @@ def test_register_sorted_run_ties_restart(top_k, bits, metric):
     _compare(built, idx, base[:40], top_k, 6)
     assert idx.heap_restarts() > 0 or top_k > 256  # (above 256 the exact heap runs from the first candidate: nothing to restart)
     idx.close()
+
+
+# ---- BASELINE sizes through size-independent properties -----------------------------------------------------------------
+@pytest.mark.parametrize("name,n,dim,nlist,bits,metric,nprobe,batch", [
+    ("cfg2_sift1m", 1_000_000, 128, 1024, 7, 0, 64, 1024),
+    ("cfg3_gist1m", 1_000_000, 960, 4096, 7, 0, 128, 4096),
+    ("cfg4_gist1m_ip_3bit", 1_000_000, 960, 4096, 3, 1, 256, 2048),
+])
+def test_full_size_baseline_configs_properties(name, n, dim, nlist, bits, metric, nprobe, batch):
+    """BASELINE.json's configurations at FULL size (1 M vectors; the index built by the device encoder, whose arrays
+    are byte-identical to the CPU build's — test_device_encoder_matches_cpu_builder), where the oracle would take minutes:
+    properties that hold at any size —
+      * a query's result does not depend on its batch (permuted batch, sub-batch, one at a time),
+      * diagnostic switches change the work, never the result (block bound off, exact all-pairs ranking, f32 GEMM,
+        exact heap from the first candidate, workgroup-per-query preparation),
+      * the host entry point (pageable buffers, sub-batch pipeline, diagnostics) returns the device path's bits,
+      * results are well-formed: counts == top_k, distances ascending (L2) / scores descending (IP), ids distinct and
+        inside the index; recall@10 against exact f32 brute force is at the level bench.py reports.
+    (bench.py itself compares two 1024-query batches of the full-size cfg3 index with the oracle on every run.)"""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    mix = bench.Mixture(torch, dev, dim, nlist, "mixture_id32", metric == 1)
+    x = mix.draw(n, 20260105)
+    cent, assign = bench.kmeans_gpu(torch, x, nlist, 2, 20260103)
+    xs = mix.draw(max(2 * nlist, 4096), 99).cpu().numpy()
+    small = rq.builder.train_with_clusters(xs, cent.cpu().numpy(), (np.arange(xs.shape[0]) % nlist).astype(np.uint32), bits, metric, 1,
+                                           20260104, True)
+    a32 = assign.to(torch.int32).contiguous()
+    idx = rq.IvfRabitqIndex.build_on_device(small.hdr_ptr, cent.cpu().numpy(), x.data_ptr(), a32.data_ptr(), n, small.t_const)
+    top_k = 10
+    q = mix.draw(batch, 20260102).contiguous()
+    qh = q.cpu().numpy()
+
+    def dev_search(qd, nq, index=idx):
+        ids = torch.empty(nq, top_k, dtype=torch.int64, device=dev)
+        sc = torch.empty(nq, top_k, dtype=torch.float32, device=dev)
+        cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+        index.search_batch_device(qd.data_ptr(), nq, dim, top_k, nprobe, ids.data_ptr(), sc.data_ptr(), cnt.data_ptr())
+        torch.cuda.synchronize(dev)
+        return ids.cpu().numpy().view(np.uint64), sc.cpu().numpy(), cnt.cpu().numpy().view(np.uint32)
+
+    ids, sc, cnt = dev_search(q, batch)
+    # well-formed
+    assert (cnt == top_k).all()
+    assert ((np.diff(sc, axis=1) >= 0) if metric == 0 else (np.diff(sc, axis=1) <= 0)).all()
+    assert (ids < n).all() and all(len(set(r.tolist())) == top_k for r in ids[::97])
+    # recall against exact brute force
+    gt = bench.exact_topk(torch, x, q, top_k, metric).cpu().numpy()
+    rec = bench.recall_of(ids, gt, top_k)
+    assert rec > (0.93 if bits == 3 else 0.95), rec
+    del x
+    torch.cuda.empty_cache()
+    # batch independence: permuted batch, a ragged sub-batch, single queries
+    perm = np.random.default_rng(5).permutation(batch)
+    pid, psc, _ = dev_search(q[torch.from_numpy(perm).to(dev)].contiguous(), batch)
+    assert np.array_equal(pid, ids[perm]) and np.array_equal(psc.view(np.uint32), sc[perm].view(np.uint32))
+    sid, ssc, _ = dev_search(q[100:357].contiguous(), 257)
+    assert np.array_equal(sid, ids[100:357]) and np.array_equal(ssc.view(np.uint32), sc[100:357].view(np.uint32))
+    for i in (0, batch // 2, batch - 1):
+        oid, osc, _ = dev_search(q[i:i + 1].contiguous(), 1)
+        assert np.array_equal(oid[0], ids[i]) and np.array_equal(osc[0].view(np.uint32), sc[i].view(np.uint32))
+    # diagnostic switches: same bits, different work
+    for opt, val, back in (("block_bound", 0, 1), ("exact_rank", 1, 0), ("f32_rank", 1, 0), ("exact_heap", 1, 0), ("wg_prep", 1, 0)):
+        idx.set_option(opt, val)
+        nq_o = 512 if opt == "exact_rank" else batch  # (the all-pairs canonical ranking is the slow one)
+        o_ids, o_sc, o_cnt = dev_search(q[:nq_o].contiguous(), nq_o)
+        idx.set_option(opt, back)
+        assert np.array_equal(o_ids, ids[:nq_o]) and np.array_equal(o_sc.view(np.uint32), sc[:nq_o].view(np.uint32)), opt
+    assert idx.rank_fallbacks() == 0
+    # host entry point (pageable buffers; sub-batches of 1024 over several lanes), with diagnostics
+    hid, hsc, hcnt, hdiag = idx.batch_search_raw(qh, rq.SearchParams(top_k, nprobe), want_diag=True)
+    assert np.array_equal(hid, ids) and np.array_equal(hsc.view(np.uint32), sc.view(np.uint32)) and np.array_equal(hcnt, cnt)
+    assert (hdiag[:, 0] >= top_k).all() and (hdiag[:, 1] > 0).all()            # estimated >= results, something was pruned
+    assert (hdiag[:, 2] >= hdiag[:, 0]).all() if bits > 1 else (hdiag[:, 2] == 0).all()  # every estimate was an ex evaluation
+    idx.close()
