@@ -103,7 +103,7 @@ constexpr int kTileBlocks = 2 * kNScan;         // 32-vector blocks per tile (on
 constexpr int kTileCand = kTileBlocks * 32;     // candidates per tile
 constexpr int kFillK = RBQ_FILL_K;                 // stream entries per scanner lane and fill step
 constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
-constexpr int kQueueCap = 512;                    // live-block FIFO (>= kTileBlocks - 1 + kWindow)
+constexpr int kQueueCap = kTileBlocks - 1 + kWindow <= 512 ? 512 : 1024; // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
 
