@@ -126,7 +126,7 @@ int rbq_index_build_device(const rbq_header* hdr, const float* centroids, const 
  *   push    `count` vectors with ids first_id .. first_id+count-1 and their cluster ids.  vectors [count][dim] f32
  *           and assign [count] u32 may each be HOST or DEVICE pointers (detected).  Chunks must arrive in ascending
  *           id order (list membership order = ascending vector index, src/ivf.rs:1141-1149).  A list that receives
- *           more vectors than announced, or an id out of range, is RBQ_INVALID_CONFIG; after an error the builder
+ *           more vectors than announced, or a cluster id >= n_lists, is RBQ_INVALID_CONFIG; after an error the builder
  *           can only be aborted.
  *   finish  requires every announced vector to have been pushed; returns the index (identical, array for array,
  *           to rbq_index_build_device over the same data), replicated on n_devices (devices[0] must be the
@@ -191,7 +191,8 @@ int rbq_posting_scan_batch(const rbq_index* idx, const float* queries, uint64_t 
  * `hip_stream` (a hipStream_t passed as void*, NULL = default stream) and returning without host
  * synchronisation: results are valid once the stream reaches this point. Each stream gets its own scratch
  * workspace inside the handle; issue calls for one stream from one host thread at a time.
- * d_filter_words may be NULL. d_diag is NULL or [nq] rbq_diag in device memory. */
+ * d_filter_words may be NULL. d_diag is NULL or [nq] rbq_diag in device memory.
+ * A handle with several replicas serves the call from the replica on the device that owns d_queries. */
 int rbq_search_batch_device(const rbq_index* idx, const float* d_queries, uint64_t nq,
                             uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
                             const uint32_t* d_filter_words, uint64_t filter_nbits,
