@@ -940,37 +940,30 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 unsigned long long todo = bt.mt;
                 n_skip += (bt.np - bt.p) - bt.ncol;
                 if (fast) {
-                    // Everything here is wave-uniform; ballots and readfirstlane say so to the compiler, which
-                    // otherwise keeps the state in VGPRs and branches through the exec mask.
+                    // One taken survivor after the other, everything in scalar registers (all of it is wave-uniform:
+                    // readlane / readfirstlane say so to the compiler): about a dozen instructions per survivor that does
+                    // not change the top-k, the insertion on top for the ones that do.  (The first form resolved all
+                    // lanes with ballots once per INSERTION — ~100 instructions each; at top_k = 100, where most
+                    // evaluated survivors are inserted, the replay wave was two thirds of the kernel.)
                     uint32_t len_s = HeapOps::uni(rh.len);
                     bool tie = false;
                     int dk = TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k) : (len_s < top_k ? 0x7f800000 : (int)HeapOps::uni((uint32_t)bag_dk));
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
-                    // The threshold only moves when an entry actually enters the run, so the entries between two
-                    // such events are resolved together: one pass of ballots per INSERTION (about a quarter of the
-                    // evaluated survivors), not per survivor.  Lane j holds taken survivor j of the stretch.
-                    const float lbv = __int_as_float(bt.v_lb), dvf = __int_as_float(v_d);
-                    const bool fin_l = (v_d & 0x7f800000) != 0x7f800000;
-                    const int kd_l = HeapOps::key(v_d);
-                    const unsigned long long fin_m = __ballot(fin_l);
-                    (void)dvf;
                     while (todo) {
-                        const unsigned long long cand = __ballot(lbv < __int_as_float(dk)) & todo; // evaluated by the reference
-                        // entries that change the run (or tie with its maximum): finite and not beyond the k-th
-                        const bool chg = fin_l && (len_s < top_k || kd_l <= HeapOps::key(dk));
-                        const unsigned long long ins = __ballot(chg) & cand;
-                        const unsigned long long before = ins ? ((1ull << __builtin_ctzll(ins)) - 1ull) : ~0ull;
-                        const unsigned long long done = todo & before; // resolved without a change of state
-                        c_skip += (uint32_t)__popcll(done & ~cand);
-                        c_ext += (uint32_t)__popcll(done & cand);
-                        c_est += (uint32_t)__popcll(done & cand & fin_m);
-                        if (!ins) break;
-                        const uint32_t j = (uint32_t)__builtin_ctzll(ins);
-                        todo &= ~((2ull << j) - 1ull);
-                        ++c_ext; ++c_est;
+                        const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const float lb = __int_as_float(__builtin_amdgcn_readlane(bt.v_lb, (int)j));
+                        if (!(lb < __int_as_float(dk))) { ++c_skip; continue; }   // `lower_bound >= distk`: skipped
+                        ++c_ext;
                         const int dbits = __builtin_amdgcn_readlane(v_d, (int)j);
+                        if ((dbits & 0x7f800000) == 0x7f800000) continue;          // non-finite distance: dropped
+                        ++c_est;
                         const int ke = HeapOps::key(dbits);
-                        if (len_s == top_k && ke == HeapOps::key(dk)) { tie = true; continue; } // which of the equal maxima leaves depends on the heap layout
+                        if (len_s == top_k) {
+                            const int kk = HeapOps::key(dk);
+                            if (ke > kk) continue;                                  // pushed and popped again: no change
+                            if (ke == kk) { tie = true; continue; }                 // which of the equal maxima leaves depends on the heap layout
+                        }
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
                         if (TR == 1) {
                             tie |= SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane);
