@@ -485,3 +485,40 @@ def test_full_size_baseline_configs_properties(name, n, dim, nlist, bits, metric
     assert (hdiag[:, 0] >= top_k).all() and (hdiag[:, 1] > 0).all()            # estimated >= results, something was pruned
     assert (hdiag[:, 2] >= hdiag[:, 0]).all() if bits > 1 else (hdiag[:, 2] == 0).all()  # every estimate was an ex evaluation
     idx.close()
+
+
+def test_create_destroy_cycles_release_device_memory():
+    """Handles, replicas, stream workspaces, pooled lanes (pinned staging included) and stream builders give their
+    device memory back: 25 create / search / destroy cycles end where they started."""
+    import torch
+    data, built = build_index(n=20000, dim=256, nlist=64, total_bits=7, seed=501)
+    q = make_dataset(300, 256, 16, 502)
+    cent, assign = rq.builder.kmeans(data, 64, 2, 503)
+    sizes = np.bincount(assign, minlength=64).astype(np.uint32)
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(q).to(dev)
+    out = (torch.empty(300, 10, dtype=torch.int64, device=dev), torch.empty(300, 10, dtype=torch.float32, device=dev),
+           torch.empty(300, dtype=torch.int32, device=dev))
+
+    def cycle():
+        idx = rq.IvfRabitqIndex.from_built(built, devices=[0, 0])
+        idx.batch_search_raw(q, rq.SearchParams(10, 8), want_diag=True)
+        streams = [torch.cuda.Stream(dev) for _ in range(3)]
+        for s in streams:
+            idx.search_batch_device(qd.data_ptr(), 300, 256, 10, 8, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), stream=s.cuda_stream)
+        torch.cuda.synchronize(dev)
+        idx.release_stream(streams[0].cuda_stream)   # the others are freed with the handle
+        idx.close()
+        sb = rq.StreamBuilder(built.hdr_ptr, cent, sizes, built.t_const)
+        sb.push(data[:5000], assign[:5000], 0)
+        sb.abort()                                   # an unfinished builder
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize(dev)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize(dev)
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    assert free0 - free1 < 64 << 20, f"device memory not returned: {(free0 - free1) >> 20} MiB after 25 cycles"
