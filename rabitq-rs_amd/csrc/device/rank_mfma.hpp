@@ -25,6 +25,9 @@
 
 namespace rbq {
 
+#ifndef RBQ_CANON_UNROLL
+#define RBQ_CANON_UNROLL 4 // 16-byte loads a lane keeps in flight in the canonical rescoring pass
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // TW = 2: 128x128 tile (64x64 per wave, 4 MFMA per k-pair); TW = 1: 64x64 tile (32x32 per wave) for small
@@ -278,7 +281,7 @@ template <int METRIC>
 __device__ __forceinline__ float canon_pair2(const float* qrot, const float* __restrict__ c, uint32_t D, uint32_t h) {
     const uint32_t Dmain = D & ~7u;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-#pragma unroll 4
+#pragma unroll RBQ_CANON_UNROLL
     for (uint32_t i = 4 * h; i < Dmain; i += 8) {
         const float4 cv = *reinterpret_cast<const float4*>(c + i);
         const float4 qv = *reinterpret_cast<const float4*>(qrot + i);
