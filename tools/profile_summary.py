@@ -60,9 +60,12 @@ for f in glob.glob(f"{d}/stats/**/*kernel_trace.csv", recursive=True):
 for k, v in durs.items():
     if "k_scan" in k:
         v.sort()
-        tail = [x[1] / 1e6 for x in v[-8:]]  # the last launches of the process = roofline leg (bound off), one stream
-        print(f"\n`{k}`: last 8 launches of the process (roofline leg, bound off, one stream): mean {statistics.mean(tail):.4f} ms, "
-              f"min {min(tail):.4f} ms — to be compared with roofline.avg_launch_ms of the bench line.")
+        # the process ends with the roofline leg (bound off, one stream): 1 set-up + 2 warm-up + 6 TIMED launches, then 2
+        # verification launches — the timed six are launches [-8:-2]
+        tail = [x[1] / 1e6 for x in v[-8:-2]]
+        print(f"\n`{k}`: the six timed launches of the roofline leg (bound off, one stream) in the kernel trace: mean "
+              f"{statistics.mean(tail):.4f} ms, min {min(tail):.4f} ms — roofline.avg_launch_ms of the same run's bench line (HIP "
+              f"events carried by the dispatch packets): {b['roofline']['avg_launch_ms']:.4f} ms." if b else "")
 
 
 def pmc(sub):
