@@ -63,9 +63,11 @@ for k, v in durs.items():
         # the process ends with the roofline leg (bound off, one stream): 1 set-up + 2 warm-up + 6 TIMED launches, then 2
         # verification launches — the timed six are launches [-8:-2]
         tail = [x[1] / 1e6 for x in v[-8:-2]]
-        print(f"\n`{k}`: the six timed launches of the roofline leg (bound off, one stream) in the kernel trace: mean "
-              f"{statistics.mean(tail):.4f} ms, min {min(tail):.4f} ms — roofline.avg_launch_ms of the same run's bench line (HIP "
-              f"events carried by the dispatch packets): {b['roofline']['avg_launch_ms']:.4f} ms." if b else "")
+        print(f"\n`{k}`: the six timed launches of the roofline leg (bound off, one stream) in the kernel trace: "
+              f"{', '.join('%.3f' % t for t in tail)} ms — median {statistics.median(tail):.4f}, mean {statistics.mean(tail):.4f}; "
+              f"roofline.avg_launch_ms of the same run's bench line (HIP events carried by the dispatch packets): "
+              f"{b['roofline']['avg_launch_ms']:.4f} ms.  (Batches differ in size by a few per cent; launches far above the median "
+              f"appear only in the tracer's timestamps.)" if b else "")
 
 
 def pmc(sub):
