@@ -66,8 +66,7 @@ for k, v in durs.items():
         print(f"\n`{k}`: the six timed launches of the roofline leg (bound off, one stream) in the kernel trace: "
               f"{', '.join('%.3f' % t for t in tail)} ms — median {statistics.median(tail):.4f}, mean {statistics.mean(tail):.4f}; "
               f"roofline.avg_launch_ms of the same run's bench line (HIP events carried by the dispatch packets): "
-              f"{b['roofline']['avg_launch_ms']:.4f} ms.  (Batches differ in size by a few per cent; launches far above the median "
-              f"appear only in the tracer's timestamps.)" if b else "")
+              f"{b['roofline']['avg_launch_ms']:.4f} ms.  (Every launch scans a different batch.)" if b else "")
 
 
 def pmc(sub):
