@@ -433,7 +433,8 @@ def main():
         dt = time.perf_counter() - t0
         index.profile_end()
         ms, launches = index.profile_stage("scan")
-        prof = {"scan_ms": ms, "scan_launches": launches, "counters": index.profile_counters(),
+        prof = {"scan_ms": ms, "scan_launches": launches, "scan_samples_ms": [round(float(v), 4) for v in index.profile_stage_samples("scan")],
+                "counters": index.profile_counters(),
                 "algorithmic_bytes": index.profile_scan_bytes()}
         for st in streams:
             index.release_stream(st.cuda_stream)
@@ -500,7 +501,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "algorithmic_bytes_per_launch": alg2, "bytes_requested_per_launch": req2, "avg_launch_ms": p2["scan_ms"],
-                    "launches": p2["scan_launches"], "ids_identical_to_product_configuration": bool(np.array_equal(ids_off, ids_all[:2])),
+                    "launches": p2["scan_launches"], "launch_ms": p2["scan_samples_ms"], "ids_identical_to_product_configuration": bool(np.array_equal(ids_off, ids_all[:2])),
                     "configuration": "block-level bound OFF (rbq_debug_set_option block_bound=0): every probed block is streamed, "
                                      "so the algorithmic bytes (SURVEY 8d: sum n_c*(D/8+12)) are the bytes moved; one stream, "
                                      "distinct query batch per launch; HIP events carried by the dispatch packets",

@@ -224,6 +224,9 @@ int rbq_index_set_rerank_vectors(rbq_index* idx, const float* vectors, uint64_t 
 void   rbq_profile_begin(rbq_index* idx);
 void   rbq_profile_end(rbq_index* idx);
 double rbq_profile_stage_ms(const rbq_index* idx, const char* stage, uint64_t* launches);
+/* Durations (ms) of the individual timed launches of a stage, in launch order (replica after replica); returns their
+ * number, writes at most `cap` of them to `out` (which may be NULL). */
+uint64_t rbq_profile_stage_samples(const rbq_index* idx, const char* stage, float* out, uint64_t cap);
 /* Algorithmic bytes (sum over probed lists of n_c*(D/8+12)) of the
  * scan launches between rbq_profile_begin/end. */
 uint64_t rbq_profile_scan_bytes(const rbq_index* idx);

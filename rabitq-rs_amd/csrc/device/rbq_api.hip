@@ -116,6 +116,7 @@ struct StageProf {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; // pairs recorded since rbq_profile_begin
     double ms = 0;
     uint64_t launches = 0;
+    std::vector<float> samples; // duration of every timed launch, in launch order
 };
 // Event pairs are created once and recycled: hipEventCreate inside the launch path cost ~15 % of the
 // overlapped throughput and broke down beyond three caller streams.
@@ -1550,7 +1551,7 @@ void rbq_profile_begin(rbq_index* h) {
         std::lock_guard<std::mutex> lk(ix->mu);
         for (auto& sp : ix->stage_prof) {
             for (auto& e : sp.ev) ix->ev_pool.give(e);
-            sp.ev.clear(); sp.ms = 0; sp.launches = 0;
+            sp.ev.clear(); sp.ms = 0; sp.launches = 0; sp.samples.clear();
         }
         for (auto& c : ix->prof_counters) c = 0;
         (void)hipMemset(ix->prof.p, 0, kProfSlots * 8);
@@ -1570,7 +1571,7 @@ void rbq_profile_end(rbq_index* h) {
         for (auto& sp : ix->stage_prof) {
             for (auto& e : sp.ev) {
                 float ms = 0;
-                if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sp.ms += ms; sp.launches++; }
+                if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sp.ms += ms; sp.launches++; sp.samples.push_back(ms); }
                 ix->ev_pool.give(e);
             }
             sp.ev.clear();
@@ -1585,6 +1586,15 @@ double rbq_profile_stage_ms(const rbq_index* h, const char* stage, uint64_t* lau
     for (const Replica* ix : h->reps) { ms += ix->stage_prof[s].ms; n += ix->stage_prof[s].launches; }
     if (launches) *launches = n;
     return n ? ms / (double)n : 0.0;
+}
+uint64_t rbq_profile_stage_samples(const rbq_index* h, const char* stage, float* out, uint64_t cap) {
+    if (!h || h->reps.empty() || !stage) return 0;
+    int s = !std::strcmp(stage, "prep") ? 0 : !std::strcmp(stage, "rank") ? 1 : !std::strcmp(stage, "select") ? 2 : !std::strcmp(stage, "scan") ? 3 : -1;
+    if (s < 0) return 0;
+    uint64_t n = 0;
+    for (const Replica* ix : h->reps)
+        for (float v : ix->stage_prof[s].samples) { if (out && n < cap) out[n] = v; ++n; }
+    return n;
 }
 uint64_t rbq_profile_scan_bytes(const rbq_index* h) {
     if (!h || h->reps.empty()) return 0;

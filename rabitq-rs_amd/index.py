@@ -101,6 +101,8 @@ def lib():
         L.rbq_host_free.argtypes = [vp]
         L.rbq_index_set_rerank_vectors.restype = C.c_int
         L.rbq_index_set_rerank_vectors.argtypes = [vp, vp, C.c_uint64]
+        L.rbq_profile_stage_samples.restype = C.c_uint64
+        L.rbq_profile_stage_samples.argtypes = [vp, C.c_char_p, vp, C.c_uint64]
         L.rbq_profile_counters.restype = C.c_int
         L.rbq_profile_counters.argtypes = [vp, vp, C.c_uint32]
         _LIB = L
@@ -289,6 +291,13 @@ class IvfRabitqIndex:
         n = C.c_uint64()
         ms = lib().rbq_profile_stage_ms(self._h, name.encode(), C.byref(n))
         return ms, n.value
+
+    def profile_stage_samples(self, name):
+        """durations (ms) of the individual timed launches of a stage between profile_begin/end"""
+        n = lib().rbq_profile_stage_samples(self._h, name.encode(), None, 0)
+        out = np.zeros(max(int(n), 1), np.float32)
+        lib().rbq_profile_stage_samples(self._h, name.encode(), out.ctypes.data, int(n))
+        return out[:int(n)]
 
     def set_option(self, name, value):
         _check(lib().rbq_debug_set_option(self._h, name.encode(), int(value)))
