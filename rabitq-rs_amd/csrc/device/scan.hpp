@@ -706,6 +706,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     RegHeap<TR> rh; // the replay wave's top-k registers: exact heap, or (same registers) the bag
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
     int bag_dk = 0x7f800000; // bits of the bag's maximum (valid once it holds top_k entries)
+    bool tie_pending = false; // replay wave: a distance tie was met, the query will be re-run with the exact heap
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
@@ -856,6 +857,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
 #ifdef RBQ_STAMPS
             STAMP(st_b); st_waitA += st_b - st_a;
 #endif
+            if (fast && s_restart) break; // a tie was met: leave the pass now (every wave reads the flag behind the same barrier)
             uint32_t S = 0;
 #pragma unroll
             for (int j = 0; j < kTileBlocks; ++j) S += __popc(s_mask[buf * kTileBlocks + j]);
@@ -885,8 +887,10 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         } else {
             // ---------------------------------------------------------------- replay wave (uniform control flow)
             STAMP(r0);
+            if (tie_pending && lane == 0) s_restart = 1u;
             lds_barrier(); // A
             RSTAMP(rp_waitA);
+            if (fast && s_restart) break;
             // compaction in stream order: block by block, lane order within the block
             for (uint32_t b = half; b < (uint32_t)kTileBlocks; b += 2) {
                 uint32_t base = 0;
@@ -976,7 +980,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                     rh.len = len_s;
                     bag_dk = dk;
                     n_skip += c_skip; n_ext += c_ext; n_est += c_est;
-                    if (tie && lane == 0) s_restart = 1u;
+                    tie_pending |= tie; // published before the next barrier A (or F), so that every wave reads the same flag after it
                 } else if (reg_heap) {
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
@@ -1074,6 +1078,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         qcount -= n;
         ++tile;
     }
+    if (tie_pending && lane == 0) s_restart = 1u; // (a tie met in the last tile)
     lds_barrier(); // F: the replay wave has consumed the last tile
     if (!s_restart) break;
     __syncthreads(); // every wave has seen the flag
@@ -1087,6 +1092,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     n_skip = 0; n_ext = 0; n_est = 0;
     rh.len = 0;
     bag_dk = 0x7f800000;
+    tie_pending = false;
     __syncthreads();
   }
     if (!scanner) {
