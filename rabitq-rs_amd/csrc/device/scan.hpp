@@ -401,18 +401,21 @@ struct RegHeap : HeapOps {
 template <int TR>
 struct BagTop {
     typedef RegHeap<TR> H;
-    // bits of the largest distance among the first `len` entries (the bag's k-th smallest once it is full)
-    static __device__ __forceinline__ int max_bits(const H& h, uint32_t len, uint32_t lane) {
-        int m = (int)0x80000000;
+    // In bag mode the distance registers hold KEYS (HeapOps::key of the distance bits: a signed-integer image of
+    // total_cmp, its own inverse) and every lane that holds no entry holds kEmpty — the key of a NaN pattern that is
+    // never inserted (non-finite distances are dropped) — so neither the maximum nor the search for it needs a
+    // "lane < len" mask.
+    static constexpr int kEmpty = (int)0x80000000;
+    static __device__ __forceinline__ void clear(H& h) {
+        h.hd = kEmpty; h.hs = 0u; h.xd = kEmpty; h.xs = 0u; h.len = 0u;
+    }
+    // key of the largest entry
+    static __device__ __forceinline__ int max_key(const H& h) {
+        int m = h.hd;
 #pragma unroll
-        for (int r = 0; r < TR; ++r) {
-            if (TR == 1 || (uint32_t)r * 64u < len) { // uniform: registers above the bag hold nothing
-                const int k = HeapOps::key(r == 0 ? h.hd : h.xd[r]);
-                m = ((uint32_t)r * 64u + lane < len && k > m) ? k : m;
-            }
-        }
+        for (int r = 1; r < TR; ++r) m = h.xd[r] > m ? h.xd[r] : m;
         // wave maximum: Hillis-Steele inside each row of 16 lanes, then row 0/2 -> 1/3, then lane 31 -> rows 2,3
-        const int lo = (int)0x80000000;
+        const int lo = kEmpty;
         int t;
         t = __builtin_amdgcn_update_dpp(lo, m, 0x111, 0xf, 0xf, false); m = t > m ? t : m;
         t = __builtin_amdgcn_update_dpp(lo, m, 0x112, 0xf, 0xf, false); m = t > m ? t : m;
@@ -420,32 +423,69 @@ struct BagTop {
         t = __builtin_amdgcn_update_dpp(lo, m, 0x118, 0xf, 0xf, false); m = t > m ? t : m;
         t = __builtin_amdgcn_update_dpp(lo, m, 0x142, 0xa, 0xf, false); m = t > m ? t : m;
         t = __builtin_amdgcn_update_dpp(lo, m, 0x143, 0xc, 0xf, false); m = t > m ? t : m;
-        return HeapOps::key(__builtin_amdgcn_readlane(m, 63)); // key() is its own inverse
+        return __builtin_amdgcn_readlane(m, 63);
     }
-    // Insert (dbits, slot) into a bag of `len` entries whose maximum has the bits `dk` (valid when len == top_k; the new
-    // key is then smaller).  Updates len and dk; returns true if an equal key was met.
-    static __device__ __forceinline__ bool insert(H& h, uint32_t& len, int& dk, uint32_t top_k, int dbits, uint32_t slot, uint32_t lane) {
-        const int ke = HeapOps::key(dbits), kmax = HeapOps::key(dk);
+    // Insert (ke, slot) into a bag of `len` entries whose largest key is `kmax` (valid when len == top_k; ke < kmax
+    // then).  Updates len and kmax.  Returns true when the maximum that leaves has an equal-keyed twin in the bag — the
+    // case in which WHICH entry the reference's pop() removes depends on the layout of its heap.  A new key equal to
+    // the maximum is caught by the caller before it gets here; a new key equal to any other entry sets a bit of `eqm`
+    // (no branch here: the caller tests the mask once per batch); sort_out() below is the safety net behind both.
+    static __device__ __forceinline__ bool insert(H& h, uint32_t& len, int& kmax, uint32_t top_k, int ke, uint32_t slot,
+                                                  unsigned long long& eqm) {
         const bool full = len == top_k;
-        bool tie = false;
         uint32_t pos = len; // append while the bag is filling
-        bool found = false;
 #pragma unroll
-        for (int r = 0; r < TR; ++r) {
-            if (TR == 1 || (uint32_t)r * 64u < len) {
-                const int k = HeapOps::key(r == 0 ? h.hd : h.xd[r]);
-                const bool in = (uint32_t)r * 64u + lane < len;
-                tie |= __ballot(in && k == ke) != 0ull;
-                if (full && !found) { // uniform: the slot of the maximum (unique: a tie at the maximum restarts the query)
-                    const unsigned long long mm = __ballot(in && k == kmax);
-                    if (mm) { pos = (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(mm); found = true; }
-                }
+        for (int r = 0; r < TR; ++r) eqm |= __ballot((r == 0 ? h.hd : h.xd[r]) == ke); // lanes holding an equal key (tested once per batch)
+        if (full) {         // uniform: the slot of the maximum
+            bool found = false;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const unsigned long long mm = __ballot((r == 0 ? h.hd : h.xd[r]) == kmax);
+                if (!found && mm) { pos = (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(mm); found = true; }
             }
         }
-        h.set(pos, dbits, slot);
+        h.set(pos, ke, slot);
         len = full ? len : len + 1u;
-        if (len == top_k) dk = max_bits(h, len, lane);
+        bool tie = false;
+        if (len == top_k) {
+            const int nk = max_key(h);
+            tie = full && nk == kmax;
+            kmax = nk;
+        }
         return tie;
+    }
+    // Sort the finished bag into d_out/s_out (ascending distances, slots): rank of every entry = number of smaller keys.
+    // Two equal keys take the same rank and leave a position unwritten: d_out is pre-filled with a NaN pattern that no
+    // entry carries, and a position still holding it afterwards reports the tie.  `s_key` is scratch for `len` keys.
+    static __device__ __forceinline__ bool sort_out(const H& h, uint32_t len, uint32_t lane, int* s_key, float* d_out, uint32_t* s_out) {
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+            if ((uint32_t)r * 64u + lane < len) {
+                s_key[r * 64 + lane] = r == 0 ? h.hd : h.xd[r];
+                d_out[r * 64 + lane] = __int_as_float(-1); // key kEmpty
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int my[TR];
+        uint32_t rank[TR];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) { my[r] = r == 0 ? h.hd : h.xd[r]; rank[r] = 0; }
+        for (uint32_t j = 0; j < len; ++j) {
+            const int kj = s_key[j];
+#pragma unroll
+            for (int r = 0; r < TR; ++r) rank[r] += kj < my[r] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+            if ((uint32_t)r * 64u + lane < len) {
+                d_out[rank[r]] = __int_as_float(HeapOps::key(my[r]));
+                s_out[rank[r]] = r == 0 ? h.hs : h.xs[r];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bool hole = false;
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+            if ((uint32_t)r * 64u + lane < len) hole |= __float_as_int(d_out[r * 64 + lane]) == -1;
+        return __ballot(hole) != 0ull;
     }
 };
 
@@ -705,6 +745,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // bag top-k (BagTop) until a distance tie shows up
     RegHeap<TR> rh; // the replay wave's top-k registers: exact heap, or (same registers) the bag
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
+    if (TR > 1 && fast) BagTop<TR>::clear(rh); // bag mode: keys, empty lanes marked
     int bag_dk = 0x7f800000; // bits of the bag's maximum (valid once it holds top_k entries)
     bool tie_pending = false; // replay wave: a distance tie was met, the query will be re-run with the exact heap
     LdsHeap lh{heap_d, heap_s, 0};
@@ -952,6 +993,8 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                     uint32_t len_s = HeapOps::uni(rh.len);
                     bool tie = false;
                     int dk = TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k) : (len_s < top_k ? 0x7f800000 : (int)HeapOps::uni((uint32_t)bag_dk));
+                    int kmax = HeapOps::key(dk); // bag: key of its maximum (valid when full)
+                    unsigned long long eqm = 0ull; // bag: lanes that held a key equal to an inserted one
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
@@ -964,7 +1007,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                         ++c_est;
                         const int ke = HeapOps::key(dbits);
                         if (len_s == top_k) {
-                            const int kk = HeapOps::key(dk);
+                            const int kk = TR == 1 ? HeapOps::key(dk) : kmax;
                             if (ke > kk) continue;                                  // pushed and popped again: no change
                             if (ke == kk) { tie = true; continue; }                 // which of the equal maxima leaves depends on the heap layout
                         }
@@ -974,13 +1017,14 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                             len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
                             dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
                         } else {
-                            tie |= BagTop<TR>::insert(rh, len_s, dk, top_k, dbits, slot, lane); // (dk stays +inf while filling)
+                            tie |= BagTop<TR>::insert(rh, len_s, kmax, top_k, ke, slot, eqm);
+                            if (len_s == top_k) dk = HeapOps::key(kmax);            // (dk stays +inf while filling)
                         }
                     }
                     rh.len = len_s;
                     bag_dk = dk;
                     n_skip += c_skip; n_ext += c_ext; n_est += c_est;
-                    tie_pending |= tie; // published before the next barrier A (or F), so that every wave reads the same flag after it
+                    tie_pending |= tie || eqm != 0ull; // published before the next barrier A (or F), so that every wave reads the same flag after it
                 } else if (reg_heap) {
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
@@ -1078,6 +1122,11 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         qcount -= n;
         ++tile;
     }
+    if (TR > 1 && !scanner && fast && !tie_pending) {
+        // the bag is sorted into heap_d/heap_s here, before the pass is declared finished: two equal distances that both
+        // stayed in the top-k show up only now (a tile buffer is free by now: scratch for the keys)
+        tie_pending = BagTop<TR>::sort_out(rh, rh.len, lane, reinterpret_cast<int*>(q_d), heap_d, heap_s);
+    }
     if (tie_pending && lane == 0) s_restart = 1u; // (a tie met in the last tile)
     lds_barrier(); // F: the replay wave has consumed the last tile
     if (!s_restart) break;
@@ -1099,26 +1148,8 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         if (fast && TR == 1) { // the sorted run: already ascending
             if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
             if (lane == 0) s_len = rh.len;
-        } else if (fast) {
-            // sort the bag once: keys to LDS (a tile buffer is free by now), rank of every entry by counting the smaller
-            // keys (distinct: no tie was met), entries to their rank
-            int* s_key = reinterpret_cast<int*>(q_d); // [<= 64*TR <= 2*kTileCand]
-            const uint32_t blen = rh.len;
-#pragma unroll
-            for (int r = 0; r < TR; ++r)
-                if ((uint32_t)r * 64u + lane < blen) s_key[r * 64 + lane] = HeapOps::key(r == 0 ? rh.hd : rh.xd[r]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                if (TR == 1 || (uint32_t)r * 64u < blen) {
-                    const int dv = r == 0 ? rh.hd : rh.xd[r];
-                    const int my = HeapOps::key(dv);
-                    uint32_t rank = 0;
-                    for (uint32_t j = 0; j < blen; ++j) rank += s_key[j] < my ? 1u : 0u;
-                    if ((uint32_t)r * 64u + lane < blen) { heap_d[rank] = __int_as_float(dv); heap_s[rank] = r == 0 ? rh.hs : rh.xs[r]; }
-                }
-            }
-            if (lane == 0) s_len = blen;
+        } else if (fast) { // the bag: sorted into heap_d/heap_s at the end of the pass (BagTop::sort_out)
+            if (lane == 0) s_len = rh.len;
         } else {
         if (reg_heap) { // spill the register heap to LDS for the final heap-sort
 #pragma unroll
