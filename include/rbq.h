@@ -233,7 +233,7 @@ uint64_t rbq_profile_scan_bytes(const rbq_index* idx);
 /* Traffic counters of the scan launches between rbq_profile_begin/end (summed over replicas), out[0..n):
  *   [0] vectors probed (sum of n_c over probed lists)   [1] block records whose sign codes were requested
  *   [2] block records whose factor rows were requested  [3] block-stream entries read (16 B each)
- *   [4] ex-code evaluations                             [5] queries scanned                */
+ *   [4] candidates whose ex codes were fetched          [5] queries scanned                */
 int rbq_profile_counters(const rbq_index* idx, uint64_t* out, uint32_t n);
 /* Which stages rbq_profile_begin/end time: bit 0 prep, 1 rank, 2 select, 3 scan (default: all four). Every timed
  * stage costs two event records per launch; a throughput measurement that only needs the dominant kernel's

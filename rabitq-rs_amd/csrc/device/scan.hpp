@@ -390,102 +390,210 @@ struct RegHeap : HeapOps {
 
 // ---- tie-free fast path of the same top-k --------------------------------------------------------------------
 // As long as no two distances in the heap are bit-identical, the reference's result does not depend on the
-// layout of its BinaryHeap: pop evicts THE maximum and into_sorted_vec has one possible order.  The replay wave
-// then keeps the top-k as an UNORDERED BAG in the RegHeap's registers (entry i in lane i % 64 of register i / 64,
-// TR registers = up to 64*TR entries; the reference's own benchmark setting is top_k = 100) together with the bits of
-// its maximum: an insertion into a full bag overwrites the maximum's slot and recomputes the maximum with one DPP
-// wave reduction — no position search, no shifting — and the bag is sorted once, when the query is finished.  (A sorted
-// run with one shift per insertion was the first form; at top_k = 100 the replay wave, a single wave per query,
-// spent 2/3 of the kernel's time in it.)  An insertion that meets an equal key reports a tie; the query is then
-// re-run from its first block with the exact BinaryHeap emulation (RegHeap while top_k < 64*TR, LdsHeap above).
+// layout of its BinaryHeap: pop evicts THE maximum and into_sorted_vec has one possible order.  Any equality the
+// fast path meets reports a tie; the query is then re-run from its first block with the exact BinaryHeap emulation
+// (RegHeap while top_k < 64*TR, LdsHeap above).
+//
+// RankRun (TR > 1: 64 <= top_k <= 256, the reference's own benchmark setting is 100): the top-k is a SORTED RUN of
+// KEYS (HeapOps::key of the distance bits: a signed-integer image of total_cmp, its own inverse) in the RegHeap's
+// registers, entry i in lane i % 64 of register i / 64, empty lanes = kHigh.  A whole refine batch (up to 64 candidates
+// in stream order, lane j = candidate j) is merged in ONE data-parallel step instead of one candidate after the other —
+// at top_k = 100 most evaluated candidates enter the top-k, and a serial insertion per candidate (~700 cycles of
+// dependent scalar/DPP work each) was two thirds of the kernel.
+//
+// The reference's loop over the batch is, with U_j = run + candidates accepted before j and t_j = k-th smallest of U_j
+// (+inf while |U_j| < k):   skip j if lb_j >= t_j;  drop j if d_j is not finite;  accept j iff d_j < t_j (then the
+// maximum leaves when |U| > k).  Order-free form, valid while every finite candidate has lb_j < d_j (the lower bound is
+// below the refined distance; for the others see the check in merge_batch, else the batch takes the serial path):
+//     accept j  <=>  d_j finite and  #{u in run: u < d_j} + #{i < j: d_i finite, d_i < d_j}  <  k.
+// Proof: (1) the lb test never changes the accepted set: lb_j >= t_j and lb_j < d_j give d_j > t_j, rejected anyway.
+// (2) d_j < t_j <=> fewer than k elements of U_j are smaller than d_j.  (3) Counting EVERY earlier finite i with
+// d_i < d_j instead of the accepted ones changes nothing: a rejected such i has d_i >= t_i >= t_j, hence d_j > t_j, and
+// the larger count still says "rejected".  The accepted set A then determines the new run: U = run + A minus its
+// |U| - k largest elements; with G(u) = #{v in U: v > u} (run entries: position from the top + #{a in A: a > u}) an
+// element stays iff G(u) >= |U| - k and its new position from the top is G(u) - (|U| - k): one scatter through LDS.
+// The diagnostics counters need the thresholds t_j themselves, so a query with diagnostics (and a batch with a
+// candidate whose lb_j >= d_j) decides A by the serial simulation below — same merge afterwards.
 template <int TR>
-struct BagTop {
+struct RankRun {
     typedef RegHeap<TR> H;
-    // In bag mode the distance registers hold KEYS (HeapOps::key of the distance bits: a signed-integer image of
-    // total_cmp, its own inverse) and every lane that holds no entry holds kEmpty — the key of a NaN pattern that is
-    // never inserted (non-finite distances are dropped) — so neither the maximum nor the search for it needs a
-    // "lane < len" mask.
-    static constexpr int kEmpty = (int)0x80000000;
-    static __device__ __forceinline__ void clear(H& h) {
-        h.hd = kEmpty; h.hs = 0u; h.xd = kEmpty; h.xs = 0u; h.len = 0u;
-    }
-    // key of the largest entry
-    static __device__ __forceinline__ int max_key(const H& h) {
-        int m = h.hd;
-#pragma unroll
-        for (int r = 1; r < TR; ++r) m = h.xd[r] > m ? h.xd[r] : m;
-        // wave maximum: Hillis-Steele inside each row of 16 lanes, then row 0/2 -> 1/3, then lane 31 -> rows 2,3
-        const int lo = kEmpty;
+    static constexpr int kHigh = 0x7fffffff; // key of a NaN pattern: never inserted (non-finite distances are dropped)
+    static constexpr int kLow = (int)0x80000000;
+    static __device__ __forceinline__ void clear(H& h) { h.hd = kHigh; h.hs = 0u; h.xd = kHigh; h.xs = 0u; h.len = 0u; }
+    static __device__ __forceinline__ int wave_max(int m) {
         int t;
-        t = __builtin_amdgcn_update_dpp(lo, m, 0x111, 0xf, 0xf, false); m = t > m ? t : m;
-        t = __builtin_amdgcn_update_dpp(lo, m, 0x112, 0xf, 0xf, false); m = t > m ? t : m;
-        t = __builtin_amdgcn_update_dpp(lo, m, 0x114, 0xf, 0xf, false); m = t > m ? t : m;
-        t = __builtin_amdgcn_update_dpp(lo, m, 0x118, 0xf, 0xf, false); m = t > m ? t : m;
-        t = __builtin_amdgcn_update_dpp(lo, m, 0x142, 0xa, 0xf, false); m = t > m ? t : m;
-        t = __builtin_amdgcn_update_dpp(lo, m, 0x143, 0xc, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(kLow, m, 0x111, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(kLow, m, 0x112, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(kLow, m, 0x114, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(kLow, m, 0x118, 0xf, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(kLow, m, 0x142, 0xa, 0xf, false); m = t > m ? t : m;
+        t = __builtin_amdgcn_update_dpp(kLow, m, 0x143, 0xc, 0xf, false); m = t > m ? t : m;
         return __builtin_amdgcn_readlane(m, 63);
     }
-    // Insert (ke, slot) into a bag of `len` entries whose largest key is `kmax` (valid when len == top_k; ke < kmax
-    // then).  Updates len and kmax.  Returns true when the maximum that leaves has an equal-keyed twin in the bag — the
-    // case in which WHICH entry the reference's pop() removes depends on the layout of its heap.  A new key equal to
-    // the maximum is caught by the caller before it gets here; a new key equal to any other entry sets a bit of `eqm`
-    // (no branch here: the caller tests the mask once per batch); sort_out() below is the safety net behind both.
-    static __device__ __forceinline__ bool insert(H& h, uint32_t& len, int& kmax, uint32_t top_k, int ke, uint32_t slot,
-                                                  unsigned long long& eqm) {
-        const bool full = len == top_k;
-        uint32_t pos = len; // append while the bag is filling
+    // Merge the batch `mt` (lane j: lower-bound bits v_lb, refined distance bits v_d, slot v_s) into the run.  `serial`
+    // forces the serial decision (exact c_skip/c_ext/c_est: diagnostics).  dk_bits <- bits of the k-th distance once the
+    // run is full.  lds_k/lds_s: top_k entries of LDS; lds_k[0..len) mirrors the run's keys between calls (the scatter
+    // of the previous merge wrote them), so a candidate's rank in the run is a lane-parallel binary search.
+    // Ties: equal keys have equal G and are scattered to the same position, which leaves another position of the new
+    // run unwritten — lds_k is pre-filled with kHigh and a position still holding it reports the tie.  (A candidate
+    // equal to the threshold counts k-1 smaller elements, is accepted and collides with its twin; equal keys that are
+    // both dropped do not matter to the reference either.)
+    static __device__ __forceinline__ bool merge_batch(H& h, uint32_t top_k, unsigned long long mt, int v_lb, int v_d, uint32_t v_s,
+                                                       uint32_t lane, bool serial, int* lds_k, uint32_t* lds_s, uint32_t& c_skip,
+                                                       uint32_t& c_ext, uint32_t& c_est, int& dk_bits
+#if RBQ_STAMPS == 4
+                                                       , unsigned long long* mst
+#define MSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); mst[i] += t_ - mst[3]; mst[3] = t_; } while (0)
+#else
+#define MSTAMP(i)
+#endif
+                                                       ) {
+#if RBQ_STAMPS == 4
+        mst[3] = __builtin_amdgcn_s_memtime();
+#endif
+        const uint32_t len = HeapOps::uni(h.len);
+        const bool taken = (mt >> lane) & 1ull;
+        const bool fin = taken && ((v_d & 0x7f800000) != 0x7f800000);
+        const int x = fin ? HeapOps::key(v_d) : kHigh;
+        const unsigned long long finm = __ballot(fin);
+        const bool odd = fin && !(__int_as_float(v_lb) < __int_as_float(v_d)); // lower bound not below the refined distance
+        const unsigned long long oddm = __ballot(odd);
+        // ---- cB = #{run < x}
+        uint32_t cB = 0;
+        if (len) {
+            for (uint32_t step = 1u << (31 - __builtin_clz(len)); step; step >>= 1) { // uniform
+                const uint32_t t = cB + step;
+                const int v = lds_k[(t <= len ? t : len) - 1u];
+                cB = (t <= len && v < x) ? t : cB;
+            }
+        }
+        // (a candidate equal to a run key would rank one above its twin instead of colliding with it: test it here)
+        bool tie = len != 0u && __ballot(fin && cB < len && lds_k[cB < len ? cB : len - 1u] == x) != 0ull;
+        MSTAMP(0);
+        // ---- one pass over the finite candidates: Q = #{candidates > own key} (run entries and candidates),
+        //      P = #{earlier candidates < x}
+        int Q[TR];
 #pragma unroll
-        for (int r = 0; r < TR; ++r) eqm |= __ballot((r == 0 ? h.hd : h.xd[r]) == ke); // lanes holding an equal key (tested once per batch)
-        if (full) {         // uniform: the slot of the maximum
+        for (int r = 0; r < TR; ++r) Q[r] = 0;
+        int QA = 0;
+        uint32_t P = 0;
+        for (unsigned long long todo = finm; todo; todo &= todo - 1ull) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+            const int s = __builtin_amdgcn_readlane(x, (int)i);
+#pragma unroll
+            for (int r = 0; r < TR; ++r) Q[r] += s > (r == 0 ? h.hd : h.xd[r]) ? 1 : 0;
+            QA += s > x ? 1 : 0;
+            P += (lane > i && s < x) ? 1u : 0u;
+        }
+        unsigned long long accm = __ballot(fin && cB + P < top_k);
+        // every rejected candidate is larger than every element that stays (it was at or above the threshold of its
+        // moment), so for those #{accepted > u} = Q(u) - #rejected; for the ones that leave the value only gets smaller
+        int nrej = __popcll(finm) - __popcll(accm);
+        if (!serial && (oddm & accm) && len + (uint32_t)__popcll(accm) > top_k) {
+            // The order-free rule took the "odd" candidates it accepts for evaluated.  They are, if lb < the threshold of
+            // their moment; that threshold is >= the one after the batch (t_end = the element with exactly `evict`
+            // elements above it), so lb < t_end for all of them confirms the rule's result (first odd candidate: everything
+            // before it is exact, so its threshold is the rule's; and so on).  Otherwise: the serial loop decides.
+            const int evict = (int)(len + (uint32_t)__popcll(accm) - top_k);
+            int tkey = kHigh;
             bool found = false;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const unsigned long long mm = __ballot((r == 0 ? h.hd : h.xd[r]) == kmax);
-                if (!found && mm) { pos = (uint32_t)r * 64u + (uint32_t)__builtin_ctzll(mm); found = true; }
+                const uint32_t idx = (uint32_t)r * 64u + lane;
+                const unsigned long long mm = __ballot(idx < len && (int)len - 1 - (int)idx + Q[r] - nrej == evict);
+                if (mm) { tkey = __builtin_amdgcn_readlane(r == 0 ? h.hd : h.xd[r], __builtin_ctzll(mm)); found = true; }
+            }
+            {
+                const unsigned long long mm = __ballot(((accm >> lane) & 1ull) && (int)len - (int)cB + QA - nrej == evict);
+                if (mm) { tkey = __builtin_amdgcn_readlane(x, __builtin_ctzll(mm)); found = true; }
+            }
+            const float tf = __int_as_float(HeapOps::key(tkey));
+            serial = !found || __ballot(odd && ((accm >> lane) & 1ull) && !(__int_as_float(v_lb) < tf)) != 0ull;
+        }
+        if (serial) { // the reference's loop itself, on the run's top entries and the accepted candidates still alive
+            uint32_t p = 0, size = len; // p: run entries that left (from the top)
+            unsigned long long alive = 0ull;
+            accm = 0ull;
+            for (unsigned long long todo = mt; todo; todo &= todo - 1ull) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                const bool full = size == top_k;
+                int tk = kHigh, bt = kLow, am = kLow;
+                if (full) {
+                    bt = p < len ? h.d_at(len - 1u - p) : kLow;
+                    am = wave_max(((alive >> lane) & 1ull) ? x : kLow);
+                    tk = bt > am ? bt : am;
+                }
+                const float tf = full ? __int_as_float(HeapOps::key(tk)) : INFINITY;
+                const float lb = __int_as_float(__builtin_amdgcn_readlane(v_lb, (int)j));
+                if (!(lb < tf)) { ++c_skip; continue; }
+                ++c_ext;
+                if (!((finm >> j) & 1ull)) continue;
+                ++c_est;
+                const int ke = __builtin_amdgcn_readlane(x, (int)j);
+                if (full) {
+                    if (ke > tk) continue;
+                    if (ke == tk) { tie = true; continue; }
+                    if (bt >= am) ++p;
+                    else alive &= ~(1ull << (uint32_t)__builtin_ctzll(__ballot(((alive >> lane) & 1ull) && x == am)));
+                } else ++size;
+                alive |= 1ull << j;
+                accm |= 1ull << j;
+            }
+            // a candidate skipped by its lower bound may be smaller than elements that stay: count the accepted only
+#pragma unroll
+            for (int r = 0; r < TR; ++r) Q[r] = 0;
+            QA = 0;
+            nrej = 0;
+            for (unsigned long long todo = accm; todo; todo &= todo - 1ull) {
+                const int s = __builtin_amdgcn_readlane(x, __builtin_ctzll(todo));
+#pragma unroll
+                for (int r = 0; r < TR; ++r) Q[r] += s > (r == 0 ? h.hd : h.xd[r]) ? 1 : 0;
+                QA += s > x ? 1 : 0;
             }
         }
-        h.set(pos, ke, slot);
-        len = full ? len : len + 1u;
-        bool tie = false;
-        if (len == top_k) {
-            const int nk = max_key(h);
-            tie = full && nk == kmax;
-            kmax = nk;
+        MSTAMP(1);
+        // ---- merge: an element stays iff G = #{elements of run + accepted above it} >= evict
+        const uint32_t macc = (uint32_t)__popcll(accm);
+        if (macc) {
+            const uint32_t total = len + macc;
+            const uint32_t evict = total > top_k ? total - top_k : 0u, nlen = total - evict;
+#pragma unroll
+            for (int r = 0; r < TR; ++r)
+                if ((uint32_t)r * 64u + lane < nlen) lds_k[r * 64 + lane] = kHigh;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const uint32_t idx = (uint32_t)r * 64u + lane;
+                const int G = (int)len - 1 - (int)idx + Q[r] - nrej;
+                if (idx < len && G >= (int)evict) {
+                    const uint32_t pos = nlen - 1u - (uint32_t)(G - (int)evict);
+                    lds_k[pos] = r == 0 ? h.hd : h.xd[r];
+                    lds_s[pos] = r == 0 ? h.hs : h.xs[r];
+                }
+            }
+            {
+                const int GA = (int)len - (int)cB + QA - nrej;
+                if (((accm >> lane) & 1ull) && GA >= (int)evict) {
+                    const uint32_t pos = nlen - 1u - (uint32_t)(GA - (int)evict);
+                    lds_k[pos] = x;
+                    lds_s[pos] = v_s;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bool hole = false;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const uint32_t idx = (uint32_t)r * 64u + lane;
+                const int kv = idx < nlen ? lds_k[idx] : kHigh;
+                const uint32_t sv = idx < nlen ? lds_s[idx] : 0u;
+                hole |= idx < nlen && kv == kHigh;
+                if (r == 0) { h.hd = kv; h.hs = sv; } else { h.xd[r] = kv; h.xs[r] = sv; }
+            }
+            tie |= __ballot(hole) != 0ull;
+            h.len = nlen;
+            if (nlen == top_k) dk_bits = HeapOps::key(h.d_at(top_k - 1u));
         }
+        MSTAMP(2);
         return tie;
-    }
-    // Sort the finished bag into d_out/s_out (ascending distances, slots): rank of every entry = number of smaller keys.
-    // Two equal keys take the same rank and leave a position unwritten: d_out is pre-filled with a NaN pattern that no
-    // entry carries, and a position still holding it afterwards reports the tie.  `s_key` is scratch for `len` keys.
-    static __device__ __forceinline__ bool sort_out(const H& h, uint32_t len, uint32_t lane, int* s_key, float* d_out, uint32_t* s_out) {
-#pragma unroll
-        for (int r = 0; r < TR; ++r)
-            if ((uint32_t)r * 64u + lane < len) {
-                s_key[r * 64 + lane] = r == 0 ? h.hd : h.xd[r];
-                d_out[r * 64 + lane] = __int_as_float(-1); // key kEmpty
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        int my[TR];
-        uint32_t rank[TR];
-#pragma unroll
-        for (int r = 0; r < TR; ++r) { my[r] = r == 0 ? h.hd : h.xd[r]; rank[r] = 0; }
-        for (uint32_t j = 0; j < len; ++j) {
-            const int kj = s_key[j];
-#pragma unroll
-            for (int r = 0; r < TR; ++r) rank[r] += kj < my[r] ? 1u : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < TR; ++r)
-            if ((uint32_t)r * 64u + lane < len) {
-                d_out[rank[r]] = __int_as_float(HeapOps::key(my[r]));
-                s_out[rank[r]] = r == 0 ? h.hs : h.xs[r];
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bool hole = false;
-#pragma unroll
-        for (int r = 0; r < TR; ++r)
-            if ((uint32_t)r * 64u + lane < len) hole |= __float_as_int(d_out[r * 64 + lane]) == -1;
-        return __ballot(hole) != 0ull;
     }
 };
 
@@ -605,7 +713,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         uint4* dst = reinterpret_cast<uint4*>(s_lut);
         for (uint32_t i = tid; i < Dc / 4; i += kScanThreads) dst[i] = src[i];
         for (uint32_t i = tid; i < qlen; i += kScanThreads) s_q[i] = i < D ? P.rot[(size_t)q * D + i] : 0.0f;
-        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; s_misc[5] = 0; s_misc[6] = 0; }
+        if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; s_misc[5] = 0; s_misc[6] = 0; s_misc[7] = 0; }
     }
     // the replay wave is the serial part of every tile: let it issue ahead of the (many) scanner waves it shares
     // its SIMD with
@@ -619,7 +727,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     uint32_t n_skip = 0, n_ext = 0, n_est = 0; // n_skip: every thread; n_ext/n_est: replay wave (uniform)
     // traffic counters of an open profile (P.prof): block records whose codes / factor rows this half-wave
     // requested, passes over the stream, ex-code evaluations (they survive an exact-heap restart: the traffic is real)
-    uint32_t p_code = 0, p_meta = 0, p_pass = 1, p_ext = 0;
+    uint32_t p_code = 0, p_meta = 0, p_pass = 1; // (candidates whose ex codes were fetched are counted in s_misc[7])
     const bool count_skips = P.diag != nullptr;
 
     // group `g` (16 lanes) refines the survivor at queue position s_batch[g] of tile buffer `buf`.  The ex
@@ -742,11 +850,11 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     uint32_t win = (uint32_t)kTileBlocks;
     // replay-wave state
     const bool reg_heap = top_k < 64u * TR;                     // exact BinaryHeap emulation in registers (else in LDS)
-    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // bag top-k (BagTop) until a distance tie shows up
+    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // sorted run (SortedRun / RankRun) until a distance tie shows up
     RegHeap<TR> rh; // the replay wave's top-k registers: exact heap, or (same registers) the bag
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
-    if (TR > 1 && fast) BagTop<TR>::clear(rh); // bag mode: keys, empty lanes marked
-    int bag_dk = 0x7f800000; // bits of the bag's maximum (valid once it holds top_k entries)
+    if (TR > 1 && fast) RankRun<TR>::clear(rh); // keys, empty lanes marked
+    int bag_dk = 0x7f800000; // RankRun: bits of the k-th distance (valid once the run holds top_k entries)
     bool tie_pending = false; // replay wave: a distance tie was met, the query will be re-run with the exact heap
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
@@ -754,7 +862,8 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     uint32_t st_nheavy = 0, st_surv = 0, st_ntile = 0, st_dead = 0;
     uint32_t st_rounds = 0;
 #define STAMP(x) x = __builtin_amdgcn_s_memtime()
-    unsigned long long rp_collect = 0, rp_ref0 = 0, rp_replay = 0, rp_waitC = 0, rp_light = 0, rp_waitA = 0, r0 = 0, r1 = 0;
+    unsigned long long rp_collect = 0, rp_ref0 = 0, rp_replay = 0, rp_waitC = 0, rp_light = 0, rp_waitA = 0, r0 = 0, r1 = 0, rp_x1 = 0, rp_x2 = 0;
+    unsigned long long mst[4] = {0, 0, 0, 0}; // RankRun::merge_batch phases (RBQ_STAMPS == 4)
 #define RSTAMP(acc) do { r1 = __builtin_amdgcn_s_memtime(); acc += r1 - r0; r0 = r1; } while (0)
 #else
 #define STAMP(x)
@@ -972,6 +1081,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                     const unsigned long long mt = __ballot(take);
                     if ((uint32_t)__popcll(m) > G) np = p + (63u - (uint32_t)__builtin_clzll(mt)) + 1u; // stop after the G-th taken
                     if (ex_bits && take) s_batch[rank] = s_list[i];
+                    if (ex_bits && P.prof && lane == 0) s_misc[7] += (uint32_t)__popcll(mt);
                     bt.p = p; bt.np = np; bt.ncol = (uint32_t)__popcll(mt); bt.e = e; bt.mt = mt; bt.v_lb = __float_as_int(lbv);
                     return bt;
                 }
@@ -984,17 +1094,38 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 if ((bt.mt >> lane) & 1ull) { v_d = __float_as_int(q_d[bt.e]); v_s = q_slot[bt.e]; }
                 unsigned long long todo = bt.mt;
                 n_skip += (bt.np - bt.p) - bt.ncol;
-                if (fast) {
+#if RBQ_STAMPS == 4
+                asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(v_d), "v"(v_s) : "memory");
+                RSTAMP(rp_x1); // the batch's distances have arrived from LDS
+#endif
+                if (fast && TR > 1) {
+                    // the whole batch in one data-parallel step (RankRun)
+                    uint32_t c_skip = 0, c_ext = 0, c_est = 0;
+                    int dk = bag_dk;
+#ifdef RBQ_STAMPS
+                    const bool serial_counts = false; // (the diag slots carry cycle stamps in this build)
+#else
+                    const bool serial_counts = count_skips;
+#endif
+                    const bool tie = RankRun<TR>::merge_batch(rh, top_k, bt.mt, bt.v_lb, v_d, v_s, lane, serial_counts,
+                                                              reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk
+#if RBQ_STAMPS == 4
+                                                              , mst
+#endif
+                                                              );
+                    bag_dk = dk;
+                    n_skip += c_skip; n_ext += c_ext; n_est += c_est;
+                    tie_pending |= tie; // published before the next barrier A (or F), so that every wave reads the same flag after it
+#if RBQ_STAMPS == 4
+                    RSTAMP(rp_x2); // the merge
+#endif
+                } else if (fast) {
                     // One taken survivor after the other, everything in scalar registers (all of it is wave-uniform:
                     // readlane / readfirstlane say so to the compiler): about a dozen instructions per survivor that does
-                    // not change the top-k, the insertion on top for the ones that do.  (The first form resolved all
-                    // lanes with ballots once per INSERTION — ~100 instructions each; at top_k = 100, where most
-                    // evaluated survivors are inserted, the replay wave was two thirds of the kernel.)
+                    // not change the top-k, the insertion on top for the ones that do.
                     uint32_t len_s = HeapOps::uni(rh.len);
                     bool tie = false;
-                    int dk = TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k) : (len_s < top_k ? 0x7f800000 : (int)HeapOps::uni((uint32_t)bag_dk));
-                    int kmax = HeapOps::key(dk); // bag: key of its maximum (valid when full)
-                    unsigned long long eqm = 0ull; // bag: lanes that held a key equal to an inserted one
+                    int dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
@@ -1007,24 +1138,18 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                         ++c_est;
                         const int ke = HeapOps::key(dbits);
                         if (len_s == top_k) {
-                            const int kk = TR == 1 ? HeapOps::key(dk) : kmax;
+                            const int kk = HeapOps::key(dk);
                             if (ke > kk) continue;                                  // pushed and popped again: no change
                             if (ke == kk) { tie = true; continue; }                 // which of the equal maxima leaves depends on the heap layout
                         }
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
-                        if (TR == 1) {
-                            tie |= SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane);
-                            len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
-                            dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
-                        } else {
-                            tie |= BagTop<TR>::insert(rh, len_s, kmax, top_k, ke, slot, eqm);
-                            if (len_s == top_k) dk = HeapOps::key(kmax);            // (dk stays +inf while filling)
-                        }
+                        tie |= SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane);
+                        len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
+                        dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
                     }
                     rh.len = len_s;
-                    bag_dk = dk;
                     n_skip += c_skip; n_ext += c_ext; n_est += c_est;
-                    tie_pending |= tie || eqm != 0ull; // published before the next barrier A (or F), so that every wave reads the same flag after it
+                    tie_pending |= tie; // published before the next barrier A (or F), so that every wave reads the same flag after it
                 } else if (reg_heap) {
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
@@ -1122,11 +1247,6 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         qcount -= n;
         ++tile;
     }
-    if (TR > 1 && !scanner && fast && !tie_pending) {
-        // the bag is sorted into heap_d/heap_s here, before the pass is declared finished: two equal distances that both
-        // stayed in the top-k show up only now (a tile buffer is free by now: scratch for the keys)
-        tie_pending = BagTop<TR>::sort_out(rh, rh.len, lane, reinterpret_cast<int*>(q_d), heap_d, heap_s);
-    }
     if (tie_pending && lane == 0) s_restart = 1u; // (a tie met in the last tile)
     lds_barrier(); // F: the replay wave has consumed the last tile
     if (!s_restart) break;
@@ -1137,7 +1257,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     }
     fast = false;
     pos = 0; qhead = 0; qcount = 0; tile = 0; win = (uint32_t)kTileBlocks;
-    p_ext += n_ext; ++p_pass;
+    ++p_pass;
     n_skip = 0; n_ext = 0; n_est = 0;
     rh.len = 0;
     bag_dk = 0x7f800000;
@@ -1145,10 +1265,16 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     __syncthreads();
   }
     if (!scanner) {
-        if (fast && TR == 1) { // the sorted run: already ascending
-            if (lane < rh.len) { heap_d[lane] = __int_as_float(rh.hd); heap_s[lane] = rh.hs; }
-            if (lane == 0) s_len = rh.len;
-        } else if (fast) { // the bag: sorted into heap_d/heap_s at the end of the pass (BagTop::sort_out)
+        if (fast) { // the sorted run: already ascending (TR > 1: keys)
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                const uint32_t i = (uint32_t)r * 64u + lane;
+                if (i < rh.len) {
+                    const int dv = r == 0 ? rh.hd : rh.xd[r];
+                    heap_d[i] = __int_as_float(TR == 1 ? dv : HeapOps::key(dv));
+                    heap_s[i] = r == 0 ? rh.hs : rh.xs[r];
+                }
+            }
             if (lane == 0) s_len = rh.len;
         } else {
         if (reg_heap) { // spill the register heap to LDS for the final heap-sort
@@ -1179,7 +1305,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             atomicAdd(P.prof + kProfStreamEntries, (unsigned long long)ns * p_pass);
             atomicAdd(P.prof + kProfQueries, 1ull);
         }
-        if (wave == (uint32_t)kNScan && lane == 0 && ex_bits) atomicAdd(P.prof + kProfExEvals, (unsigned long long)(p_ext + n_ext));
+        if (wave == (uint32_t)kNScan && lane == 0 && ex_bits) atomicAdd(P.prof + kProfExEvals, (unsigned long long)s_misc[7]);
     }
     const uint32_t len = s_len;
     for (uint32_t i = tid; i < top_k; i += kScanThreads) {
@@ -1209,6 +1335,13 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     }
     if (wave == (uint32_t)kNScan && lane == 0) {
         P.out_counts[q] = len;
+#if RBQ_STAMPS == 4
+        if (P.diag) {
+            P.diag[(size_t)q * 3 + 0] = (rp_x1 & 0xffffffffull) | (rp_x2 << 32);
+            P.diag[(size_t)q * 3 + 1] = (mst[0] & 0xffffffffull) | (mst[1] << 32);
+            P.diag[(size_t)q * 3 + 2] = (mst[2] & 0xffffffffull) | (rp_waitA << 32);
+        }
+#endif
 #if RBQ_STAMPS == 2
         if (P.diag) {
             P.diag[(size_t)q * 3 + 0] = (rp_collect & 0xffffffffull) | (rp_ref0 << 32);

@@ -28,6 +28,12 @@ def _compare(built, idx, queries, top_k, nprobe, filter_words=None, filter_nbits
         np.testing.assert_allclose(sc[q, :c], osc[q, :c], rtol=RTOL, atol=0)
         assert np.isnan(sc[q, c:]).all() and (ids[q, c:] == np.iinfo(np.uint64).max).all()
     assert np.array_equal(diag, odiag), "SearchDiagnostics counters differ"
+    # the same call without diagnostics: k_scan then merges whole refine batches data-parallel for 64 <= top_k <= 256
+    # (RankRun, scan.hpp) and keeps the block-level bound under a filter — results must not change by a bit
+    ids2, sc2, cnt2, _ = idx.batch_search_raw(queries, rq.SearchParams(top_k, nprobe), filter_words, filter_nbits,
+                                              want_diag=False)
+    assert np.array_equal(cnt2, cnt) and np.array_equal(ids2, ids), "results differ without diagnostics"
+    assert np.array_equal(sc2.view(np.uint32), sc.view(np.uint32)), "scores differ without diagnostics"
     return ids, sc, cnt
 
 

@@ -21,6 +21,10 @@ if os.environ.get('RBQ_STAMPS_MODE') == '3':
     lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
     print('scanner wave 0 cycles/query: lookups %.0f  waitA %.0f  live tiles %.1f  survivors %.0f  fill %.0f  heavy tiles %.1f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
     sys.exit(0)
+if os.environ.get('RBQ_STAMPS_MODE') == '4':
+    lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
+    print('replay wave cycles/query: batch data from LDS %.0f  merge %.0f = rank search %.0f + candidate pass %.0f + scatter/reload %.0f;  waitA %.0f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
+    sys.exit(0)
 if os.environ.get('RBQ_STAMPS_MODE') == '2':
     lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
     print('replay wave cycles/query: collect %.0f  round0 refine %.0f  replay %.0f  waitC %.0f  light tiles %.0f  waitA %.0f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
