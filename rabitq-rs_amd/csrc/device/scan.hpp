@@ -399,21 +399,29 @@ struct RegHeap : HeapOps {
 // registers, entry i in lane i % 64 of register i / 64, empty lanes = kHigh.  A whole refine batch (up to 64 candidates
 // in stream order, lane j = candidate j) is merged in ONE data-parallel step instead of one candidate after the other —
 // at top_k = 100 most evaluated candidates enter the top-k, and a serial insertion per candidate (~700 cycles of
-// dependent scalar/DPP work each) was two thirds of the kernel.
+// dependent scalar/DPP work each on a SIMD shared with the refining waves) was two thirds of the kernel.
 //
 // The reference's loop over the batch is, with U_j = run + candidates accepted before j and t_j = k-th smallest of U_j
 // (+inf while |U_j| < k):   skip j if lb_j >= t_j;  drop j if d_j is not finite;  accept j iff d_j < t_j (then the
-// maximum leaves when |U| > k).  Order-free form, valid while every finite candidate has lb_j < d_j (the lower bound is
-// below the refined distance; for the others see the check in merge_batch, else the batch takes the serial path):
-//     accept j  <=>  d_j finite and  #{u in run: u < d_j} + #{i < j: d_i finite, d_i < d_j}  <  k.
-// Proof: (1) the lb test never changes the accepted set: lb_j >= t_j and lb_j < d_j give d_j > t_j, rejected anyway.
-// (2) d_j < t_j <=> fewer than k elements of U_j are smaller than d_j.  (3) Counting EVERY earlier finite i with
-// d_i < d_j instead of the accepted ones changes nothing: a rejected such i has d_i >= t_i >= t_j, hence d_j > t_j, and
-// the larger count still says "rejected".  The accepted set A then determines the new run: U = run + A minus its
-// |U| - k largest elements; with G(u) = #{v in U: v > u} (run entries: position from the top + #{a in A: a > u}) an
-// element stays iff G(u) >= |U| - k and its new position from the top is G(u) - (|U| - k): one scatter through LDS.
-// The diagnostics counters need the thresholds t_j themselves, so a query with diagnostics (and a batch with a
-// candidate whose lb_j >= d_j) decides A by the serial simulation below — same merge afterwards.
+// maximum leaves when |U| > k).  Its final top-k F is the k smallest of run + A (A = accepted candidates), t_end = max F.
+// Claim: F = the k smallest of  run + ALL finite candidates of the batch  (F'), provided every candidate o with
+// lb_o >= d_o ("odd": lower bound not below the refined distance) that is in F' has lb_o < max F'.
+// Proof: thresholds only shrink, and the world W' that accepts everything has the smallest ones: t_j >= t'_j >= max F'.
+// (1) a member s of F' that is not odd: d_s <= max F' <= t_s and lb_s < d_s, so the reference evaluates and accepts it
+// (d_s == t_s is a tie, see below); an odd member: lb_o < max F' <= t_o by the proviso, same conclusion.  So F' is inside
+// run + A.  (2) a candidate outside A was skipped (d > lb >= t_j, or odd and then outside F' by (1)... else the proviso
+// fails) or rejected (d > t_j): it is >= t_j >= t_end, so leaving it out or putting it in does not change the k
+// smallest.  Hence F = F'.  No acceptance decision, no thresholds — one merge:
+//     G(u) = #{elements of run + candidates above u}:  run entries: position from the top + #{candidates > u};
+//     candidates: #{run entries > x} + #{candidates > x};  with E = max(0, |run| + |candidates| - k), u stays iff
+//     G(u) >= E, and its new position from the top is G(u) - E.  One scatter through LDS.
+// When the proviso fails (or diagnostics want the exact c_skip/c_ext/c_est, which need the thresholds themselves) the
+// batch is decided by the serial simulation below and merged the same way.
+// Ties (the reference's result then depends on the layout of its heap; any of these reports a tie): two candidates with
+// equal keys get the same G and are scattered to the same position, which leaves another position unwritten (lds_k is
+// pre-filled with kHigh); a candidate equal to a run key lands next to it (neighbour check after the reload); an element
+// that leaves with the same key as the new maximum (checked against the old registers).  Equal keys that both leave do
+// not matter to the reference either.
 template <int TR>
 struct RankRun {
     typedef RegHeap<TR> H;
@@ -432,12 +440,7 @@ struct RankRun {
     }
     // Merge the batch `mt` (lane j: lower-bound bits v_lb, refined distance bits v_d, slot v_s) into the run.  `serial`
     // forces the serial decision (exact c_skip/c_ext/c_est: diagnostics).  dk_bits <- bits of the k-th distance once the
-    // run is full.  lds_k/lds_s: top_k entries of LDS; lds_k[0..len) mirrors the run's keys between calls (the scatter
-    // of the previous merge wrote them), so a candidate's rank in the run is a lane-parallel binary search.
-    // Ties: equal keys have equal G and are scattered to the same position, which leaves another position of the new
-    // run unwritten — lds_k is pre-filled with kHigh and a position still holding it reports the tie.  (A candidate
-    // equal to the threshold counts k-1 smaller elements, is accepted and collides with its twin; equal keys that are
-    // both dropped do not matter to the reference either.)
+    // run is full.  lds_k/lds_s: scratch for top_k entries.  Returns true if an equal key was met.
     static __device__ __forceinline__ bool merge_batch(H& h, uint32_t top_k, unsigned long long mt, int v_lb, int v_d, uint32_t v_s,
                                                        uint32_t lane, bool serial, int* lds_k, uint32_t* lds_s, uint32_t& c_skip,
                                                        uint32_t& c_ext, uint32_t& c_est, int& dk_bits
@@ -458,57 +461,48 @@ struct RankRun {
         const unsigned long long finm = __ballot(fin);
         const bool odd = fin && !(__int_as_float(v_lb) < __int_as_float(v_d)); // lower bound not below the refined distance
         const unsigned long long oddm = __ballot(odd);
-        // ---- cB = #{run < x}
-        uint32_t cB = 0;
-        if (len) {
-            for (uint32_t step = 1u << (31 - __builtin_clz(len)); step; step >>= 1) { // uniform
-                const uint32_t t = cB + step;
-                const int v = lds_k[(t <= len ? t : len) - 1u];
-                cB = (t <= len && v < x) ? t : cB;
-            }
-        }
-        // (a candidate equal to a run key would rank one above its twin instead of colliding with it: test it here)
-        bool tie = len != 0u && __ballot(fin && cB < len && lds_k[cB < len ? cB : len - 1u] == x) != 0ull;
-        MSTAMP(0);
-        // ---- one pass over the finite candidates: Q = #{candidates > own key} (run entries and candidates),
-        //      P = #{earlier candidates < x}
+        // ---- one pass over the finite candidates i (s = its key): Q = #{candidates > own key} for run entries and
+        //      candidates; the same compare, counted over the wave, is #{run entries < s} for lane i (empty lanes hold
+        //      kHigh: never below s)
         int Q[TR];
 #pragma unroll
         for (int r = 0; r < TR; ++r) Q[r] = 0;
         int QA = 0;
-        uint32_t P = 0;
+        uint32_t cB = 0;
         for (unsigned long long todo = finm; todo; todo &= todo - 1ull) {
             const uint32_t i = (uint32_t)__builtin_ctzll(todo);
             const int s = __builtin_amdgcn_readlane(x, (int)i);
+            uint32_t cnt = 0;
 #pragma unroll
-            for (int r = 0; r < TR; ++r) Q[r] += s > (r == 0 ? h.hd : h.xd[r]) ? 1 : 0;
+            for (int r = 0; r < TR; ++r) {
+                const bool gt = s > (r == 0 ? h.hd : h.xd[r]);
+                Q[r] += gt ? 1 : 0;
+                cnt += (uint32_t)__popcll(__ballot(gt));
+            }
             QA += s > x ? 1 : 0;
-            P += (lane > i && s < x) ? 1u : 0u;
+            cB = lane == i ? cnt : cB;
         }
-        unsigned long long accm = __ballot(fin && cB + P < top_k);
-        // every rejected candidate is larger than every element that stays (it was at or above the threshold of its
-        // moment), so for those #{accepted > u} = Q(u) - #rejected; for the ones that leave the value only gets smaller
-        int nrej = __popcll(finm) - __popcll(accm);
-        if (!serial && (oddm & accm) && len + (uint32_t)__popcll(accm) > top_k) {
-            // The order-free rule took the "odd" candidates it accepts for evaluated.  They are, if lb < the threshold of
-            // their moment; that threshold is >= the one after the batch (t_end = the element with exactly `evict`
-            // elements above it), so lb < t_end for all of them confirms the rule's result (first odd candidate: everything
-            // before it is exact, so its threshold is the rule's; and so on).  Otherwise: the serial loop decides.
-            const int evict = (int)(len + (uint32_t)__popcll(accm) - top_k);
+        MSTAMP(0);
+        bool tie = false;
+        unsigned long long accm = finm; // candidates merged
+        const uint32_t nfin = (uint32_t)__popcll(finm);
+        if (!serial && oddm && len + nfin > top_k) {
+            // the proviso: odd candidates that stay must have lb < t_end' = the element with exactly E elements above it
+            const int E = (int)(len + nfin - top_k);
             int tkey = kHigh;
             bool found = false;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 const uint32_t idx = (uint32_t)r * 64u + lane;
-                const unsigned long long mm = __ballot(idx < len && (int)len - 1 - (int)idx + Q[r] - nrej == evict);
+                const unsigned long long mm = __ballot(idx < len && (int)len - 1 - (int)idx + Q[r] == E);
                 if (mm) { tkey = __builtin_amdgcn_readlane(r == 0 ? h.hd : h.xd[r], __builtin_ctzll(mm)); found = true; }
             }
             {
-                const unsigned long long mm = __ballot(((accm >> lane) & 1ull) && (int)len - (int)cB + QA - nrej == evict);
+                const unsigned long long mm = __ballot(fin && (int)len - (int)cB + QA == E);
                 if (mm) { tkey = __builtin_amdgcn_readlane(x, __builtin_ctzll(mm)); found = true; }
             }
             const float tf = __int_as_float(HeapOps::key(tkey));
-            serial = !found || __ballot(odd && ((accm >> lane) & 1ull) && !(__int_as_float(v_lb) < tf)) != 0ull;
+            serial = !found || __ballot(odd && (int)len - (int)cB + QA >= E && !(__int_as_float(v_lb) < tf)) != 0ull;
         }
         if (serial) { // the reference's loop itself, on the run's top entries and the accepted candidates still alive
             uint32_t p = 0, size = len; // p: run entries that left (from the top)
@@ -543,7 +537,6 @@ struct RankRun {
 #pragma unroll
             for (int r = 0; r < TR; ++r) Q[r] = 0;
             QA = 0;
-            nrej = 0;
             for (unsigned long long todo = accm; todo; todo &= todo - 1ull) {
                 const int s = __builtin_amdgcn_readlane(x, __builtin_ctzll(todo));
 #pragma unroll
@@ -552,7 +545,7 @@ struct RankRun {
             }
         }
         MSTAMP(1);
-        // ---- merge: an element stays iff G = #{elements of run + accepted above it} >= evict
+        // ---- merge: an element stays iff G = #{elements of run + merged candidates above it} >= E
         const uint32_t macc = (uint32_t)__popcll(accm);
         if (macc) {
             const uint32_t total = len + macc;
@@ -560,35 +553,49 @@ struct RankRun {
 #pragma unroll
             for (int r = 0; r < TR; ++r)
                 if ((uint32_t)r * 64u + lane < nlen) lds_k[r * 64 + lane] = kHigh;
+            int G[TR];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 const uint32_t idx = (uint32_t)r * 64u + lane;
-                const int G = (int)len - 1 - (int)idx + Q[r] - nrej;
-                if (idx < len && G >= (int)evict) {
-                    const uint32_t pos = nlen - 1u - (uint32_t)(G - (int)evict);
+                G[r] = idx < len ? (int)len - 1 - (int)idx + Q[r] : -1;
+                if (G[r] >= (int)evict) {
+                    const uint32_t pos = nlen - 1u - (uint32_t)(G[r] - (int)evict);
                     lds_k[pos] = r == 0 ? h.hd : h.xd[r];
                     lds_s[pos] = r == 0 ? h.hs : h.xs[r];
                 }
             }
-            {
-                const int GA = (int)len - (int)cB + QA - nrej;
-                if (((accm >> lane) & 1ull) && GA >= (int)evict) {
-                    const uint32_t pos = nlen - 1u - (uint32_t)(GA - (int)evict);
-                    lds_k[pos] = x;
-                    lds_s[pos] = v_s;
-                }
+            // (a run entry equal to x counts as above it: the pair lands side by side)
+            const int GA = ((accm >> lane) & 1ull) ? (int)len - (int)cB + QA : -1;
+            if (GA >= (int)evict) {
+                const uint32_t pos = nlen - 1u - (uint32_t)(GA - (int)evict);
+                lds_k[pos] = x;
+                lds_s[pos] = v_s;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            bool hole = false;
+            if (evict) {
+                // an element that leaves with the key of the new maximum: which of the two the reference keeps depends on
+                // the layout of its heap
+                const int newmax = lds_k[nlen - 1u];
+                bool twin = GA >= 0 && GA < (int)evict && x == newmax;
+#pragma unroll
+                for (int r = 0; r < TR; ++r) twin |= G[r] >= 0 && G[r] < (int)evict && (r == 0 ? h.hd : h.xd[r]) == newmax;
+                tie |= __ballot(twin) != 0ull;
+            }
+            bool bad = false; // an unwritten position, or a key not above its lower neighbour
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
                 const uint32_t idx = (uint32_t)r * 64u + lane;
                 const int kv = idx < nlen ? lds_k[idx] : kHigh;
                 const uint32_t sv = idx < nlen ? lds_s[idx] : 0u;
-                hole |= idx < nlen && kv == kHigh;
+                int below = __builtin_amdgcn_update_dpp(kLow, kv, 0x138, 0xf, 0xf, false); // wave_shr:1
+                if (r > 0) {
+                    const int carry = __builtin_amdgcn_readlane(r == 1 ? h.hd : h.xd[r - 1], 63);
+                    below = lane == 0 ? carry : below;
+                }
+                bad |= idx < nlen && (kv == kHigh || !(below < kv));
                 if (r == 0) { h.hd = kv; h.hs = sv; } else { h.xd[r] = kv; h.xs[r] = sv; }
             }
-            tie |= __ballot(hole) != 0ull;
+            tie |= __ballot(bad) != 0ull;
             h.len = nlen;
             if (nlen == top_k) dk_bits = HeapOps::key(h.d_at(top_k - 1u));
         }
