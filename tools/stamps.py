@@ -23,7 +23,7 @@ if os.environ.get('RBQ_STAMPS_MODE') == '3':
     sys.exit(0)
 if os.environ.get('RBQ_STAMPS_MODE') == '4':
     lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
-    print('replay wave cycles/query: batch data from LDS %.0f  merge %.0f = rank search %.0f + candidate pass %.0f + scatter/reload %.0f;  waitA %.0f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
+    print('replay wave cycles/query: batch data from LDS %.0f  merge %.0f = candidate pass %.0f + proviso/serial decision %.0f + scatter/reload/checks %.0f;  waitA %.0f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
     sys.exit(0)
 if os.environ.get('RBQ_STAMPS_MODE') == '2':
     lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
