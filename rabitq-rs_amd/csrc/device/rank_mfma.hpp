@@ -355,12 +355,17 @@ __device__ __forceinline__ void canon_pair2_ip_l2(const float* qrot, const float
     dot = s0; l2 = s1;
 }
 
+#ifdef RBQ_SEL_WAVES // experiment: waves per SIMD as register target of k_select_mfma
+#define RBQ_SEL_BOUNDS __launch_bounds__(kThreads, RBQ_SEL_WAVES)
+#else
+#define RBQ_SEL_BOUNDS __launch_bounds__(kThreads)
+#endif
 // dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when RM == 1) |
 //              pgeo[4][nprobe] u32 (only when `stage`: g_add, g_err, first block, vector count of every probe)
 // RM: where the query's row of approximate scores lives during the selection passes — 2: in registers (nlist <=
 // 4096, 16 per thread), 1: staged in LDS, 0: re-read from global memory.
 template <int RM>
-__global__ __launch_bounds__(kThreads) void k_select_mfma(float* approx, uint32_t nlist, uint32_t nprobe,
+__global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint32_t nprobe,
                                                           uint32_t cap2, int row_in_lds, int metric, const float* __restrict__ rot,
                                                           const float* __restrict__ cent, uint32_t D,
                                                           const QueryConsts* __restrict__ consts, float cnorm2_max,

@@ -1064,6 +1064,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             // a round takes the next survivors whose lb is below the CURRENT true threshold (a superset of the
             // ones the reference evaluates, since the threshold only shrinks), refines them in parallel and then
             // replays the examined stretch against the running threshold.
+            uint32_t n_ref_tile = 0; // candidates taken for refinement in this tile (traffic counter)
             struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
             auto cur_distk = [&]() -> float {
                 if (fast) return rh.len < top_k ? INFINITY : __int_as_float(TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, rh.len, top_k) : bag_dk);
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                     const unsigned long long mt = __ballot(take);
                     if ((uint32_t)__popcll(m) > G) np = p + (63u - (uint32_t)__builtin_clzll(mt)) + 1u; // stop after the G-th taken
                     if (ex_bits && take) s_batch[rank] = s_list[i];
-                    if (ex_bits && P.prof && lane == 0) s_misc[7] += (uint32_t)__popcll(mt);
+                    n_ref_tile += (uint32_t)__popcll(mt);
                     bt.p = p; bt.np = np; bt.ncol = (uint32_t)__popcll(mt); bt.e = e; bt.mt = mt; bt.v_lb = __float_as_int(lbv);
                     return bt;
                 }
@@ -1240,7 +1241,10 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             }
             {
                 const float tnew = cur_distk();
-                if (lane == 0) s_T = tnew;
+                if (lane == 0) {
+                    s_T = tnew;
+                    if (ex_bits && P.prof) s_misc[7] += n_ref_tile;
+                }
             }
             if (heavy) {
                 if (lane == 0) s_nbatch = kBatchDone;
