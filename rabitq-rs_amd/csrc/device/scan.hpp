@@ -857,10 +857,13 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     uint32_t win = (uint32_t)kTileBlocks;
     // replay-wave state
     const bool reg_heap = top_k < 64u * TR;                     // exact BinaryHeap emulation in registers (else in LDS)
+    // RankRun from top_k = 64; below, the one-register sorted run (RankRun there costs the hot kernel 20 bytes of scratch at
+    // five waves per SIMD, and at top_k = 10 most candidates are rejected by one scalar compare anyway)
+    constexpr bool kRank = TR > 1;
     bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // sorted run (SortedRun / RankRun) until a distance tie shows up
     RegHeap<TR> rh; // the replay wave's top-k registers: exact heap, or (same registers) the bag
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
-    if (TR > 1 && fast) RankRun<TR>::clear(rh); // keys, empty lanes marked
+    if (kRank && fast) RankRun<TR>::clear(rh); // keys, empty lanes marked
     int bag_dk = 0x7f800000; // RankRun: bits of the k-th distance (valid once the run holds top_k entries)
     bool tie_pending = false; // replay wave: a distance tie was met, the query will be re-run with the exact heap
     LdsHeap lh{heap_d, heap_s, 0};
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             uint32_t n_ref_tile = 0; // candidates taken for refinement in this tile (traffic counter)
             struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
             auto cur_distk = [&]() -> float {
-                if (fast) return rh.len < top_k ? INFINITY : __int_as_float(TR == 1 ? SortedRun<TR>::kth(rh.hd, rh.xd, rh.len, top_k) : bag_dk);
+                if (fast) return rh.len < top_k ? INFINITY : __int_as_float(!kRank ? SortedRun<TR>::kth(rh.hd, rh.xd, rh.len, top_k) : bag_dk);
                 return reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
                                 : (lh.len < top_k ? INFINITY : heap_d[0]);
             };
@@ -1106,7 +1109,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(v_d), "v"(v_s) : "memory");
                 RSTAMP(rp_x1); // the batch's distances have arrived from LDS
 #endif
-                if (fast && TR > 1) {
+                if (fast && kRank) {
                     // the whole batch in one data-parallel step (RankRun)
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     int dk = bag_dk;
@@ -1282,7 +1285,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 const uint32_t i = (uint32_t)r * 64u + lane;
                 if (i < rh.len) {
                     const int dv = r == 0 ? rh.hd : rh.xd[r];
-                    heap_d[i] = __int_as_float(TR == 1 ? dv : HeapOps::key(dv));
+                    heap_d[i] = __int_as_float(!kRank ? dv : HeapOps::key(dv));
                     heap_s[i] = r == 0 ? rh.hs : rh.xs[r];
                 }
             }
