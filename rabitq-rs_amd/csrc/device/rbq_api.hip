@@ -899,7 +899,8 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     uint32_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
     if (nprobe > nlist) nprobe = nlist;
     if (nprobe > 4096) return fail(RBQ_INVALID_CONFIG, "nprobe > 4096 is not supported by the GPU probe selector");
-    if (top_k > 4096) return fail(RBQ_INVALID_CONFIG, "top_k > 4096 is not supported by the GPU top-k stage");
+    if (top_k > kTopKMax || scan_lds_bytes(Dc, D, ix->ex_bits, top_k) > kLdsPerWorkgroupMax)
+        return fail(RBQ_INVALID_CONFIG, "top_k > 16384 is not supported by the GPU top-k stage (the exact heap lives in the LDS of one compute unit)");
     if (ix->rerank && top_k > 1024) return fail(RBQ_INVALID_CONFIG, "rerank supports top_k <= 1024");
     const uint64_t wl_stride = std::max<uint64_t>(ix->nblk_desc_prefix[nprobe], 1);
 
@@ -1423,7 +1424,8 @@ int rbq_posting_scan_batch(const rbq_index* ch, const float* queries, uint64_t n
     if (nq == 0) return RBQ_OK;
     if (!queries || !list_ids || !list_counts || !out_ids || !out_scores || !out_counts) return fail(RBQ_INVALID_CONFIG, "null buffer");
     if (top_k == 0) { std::memset(out_counts, 0, nq * 4); return RBQ_OK; }
-    if (top_k > 4096) return fail(RBQ_INVALID_CONFIG, "top_k > 4096 is not supported by the GPU top-k stage");
+    if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, ix->ex_bits, top_k) > kLdsPerWorkgroupMax)
+        return fail(RBQ_INVALID_CONFIG, "top_k > 16384 is not supported by the GPU top-k stage (the exact heap lives in the LDS of one compute unit)");
     if (max_lists == 0) {
         std::memset(out_counts, 0, nq * 4);
         for (uint64_t i = 0; i < nq * top_k; ++i) { out_ids[i] = ~0ull; out_scores[i] = NAN; }

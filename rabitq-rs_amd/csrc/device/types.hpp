@@ -106,6 +106,8 @@ constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
 constexpr int kQueueCap = kTileBlocks - 1 + kWindow <= 512 ? 512 : 1024; // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
+constexpr uint32_t kTopKMax = 16384;              // largest top_k at all: above kTopKRegMax the exact heap is an LDS array of top_k + 1 entries
+constexpr size_t kLdsPerWorkgroupMax = 160 * 1024; // LDS of one compute unit (gfx950)
 
 // Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 units of 16 B, stored [unit][lane][16 B].
 // Lane l holds the codes of dims 16t+l (t = 0..D/16-1); unit j packs codes t = j*CPU .. j*CPU+CPU-1 as a

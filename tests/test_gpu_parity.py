@@ -517,14 +517,28 @@ def test_large_nprobe_select_paths(nprobe):
     idx.close()
 
 
-@pytest.mark.parametrize("top_k", [63, 64, 500, 4096])
+@pytest.mark.parametrize("top_k", [63, 64, 500, 4096, 16384])
 def test_large_top_k(top_k):
-    """top_k < 64 keeps the heap in registers, top_k >= 64 in LDS (exact BinaryHeap emulation, one lane); 4096 is the
+    """top_k < 64 keeps the heap in registers, top_k >= 64 in LDS (exact BinaryHeap emulation, one lane); 16384 is the
     documented limit and exceeds the number of probed candidates here (counts < top_k, NaN / u64::MAX padding)."""
     data, built = build_index(n=6000, dim=64, nlist=24, total_bits=7, seed=71)
     idx = rq.IvfRabitqIndex.from_built(built)
     q = make_dataset(12, 64, 6, 72)
     _compare(built, idx, q, top_k, 8)
+    idx.close()
+
+
+def test_top_k_6000_with_evictions_and_limit():
+    """A heap of 6000 entries in LDS that fills up and evicts (every list probed: 20 000 candidates per query), and the
+    documented limit: top_k 16385 is RBQ_INVALID_CONFIG."""
+    data, built = build_index(n=20000, dim=64, nlist=16, total_bits=3, seed=73)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(6, 64, 6, 74)
+    ids, sc, cnt = _compare(built, idx, q, 6000, 16)
+    assert (cnt == 6000).all()
+    with pytest.raises(rq.RabitqError) as e:
+        idx.batch_search_raw(q, rq.SearchParams(16385, 4))
+    assert e.value.kind == "InvalidConfig" and "16384" in e.value.detail
     idx.close()
 
 
