@@ -156,6 +156,42 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
 // the stages h < EPL are register butterflies and the stages h = EPL*m (m = 1..32) exchange with lane ^ m.  Same
 // butterflies in the same stage order as fht_lds (out[j] = x[j] + x[j+h], out[j+h] = x[j] - x[j+h]), followed by
 // the reference's rescale x * fac.
+// value of lane ^ M: DPP inside a row of 16 lanes (quad_perm for 1 and 2; row_shl:4 / row_shr:4 on alternate quads for 4;
+// row_ror:8 for 8), gfx950's v_permlane16_swap / v_permlane32_swap between rows and halves (semantics probed with
+// tests/diag/micro/permlane_probe.hip) — no LDS round trip (the first form used ds_bpermute for every stage: 48 of them
+// per transform, with one wave per SIMD every one of their latencies was exposed)
+template <int M>
+__device__ __forceinline__ float lane_xor(float v, uint32_t lane) {
+    const int vi = __float_as_int(v);
+    if (M == 1) return __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xB1, 0xf, 0xf, false)); // quad_perm [1,0,3,2]
+    if (M == 2) return __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x4E, 0xf, 0xf, false)); // quad_perm [2,3,0,1]
+    if (M == 4) {
+        int t = __builtin_amdgcn_update_dpp(vi, vi, 0x104, 0xf, 0x5, false);                       // quads 0,2 <- lane + 4
+        t = __builtin_amdgcn_update_dpp(t, vi, 0x114, 0xf, 0xa, false);                            // quads 1,3 <- lane - 4
+        return __int_as_float(t);
+    }
+    if (M == 8) return __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x128, 0xf, 0xf, false)); // row_ror:8
+    if (M == 16) { // r[0] = rows {0,0,2,2} of v, r[1] = rows {1,1,3,3}
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)vi, (unsigned)vi, false, false);
+        return __int_as_float((int)((lane & 16u) ? r[0] : r[1]));
+    }
+    // M == 32: r[0] = the lower half twice, r[1] = the upper half twice
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)vi, (unsigned)vi, false, false);
+    return __int_as_float((int)((lane & 32u) ? r[0] : r[1]));
+}
+
+// stage h = EPL * M of the transform for this lane's EPL elements: lower partner x + y, upper partner x - y (= p + (-v))
+template <int EPL, int M>
+__device__ __forceinline__ void fht_exchange(float (&v)[EPL], uint32_t lane) {
+    const bool upper = (lane & (uint32_t)M) != 0;
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const float p = lane_xor<M>(v[k], lane);
+        const float sv = upper ? -v[k] : v[k];
+        v[k] = p + sv;
+    }
+}
+
 template <int EPL>
 __device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) {
     float v[EPL];
@@ -178,15 +214,12 @@ __device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) 
                 v[k] = a + b;
                 v[k + h] = a - b;
             }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const bool upper = (lane & (uint32_t)m) != 0;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            const float p = __shfl_xor(v[k], m, 64);
-            v[k] = upper ? (p - v[k]) : (v[k] + p);
-        }
-    }
+    fht_exchange<EPL, 1>(v, lane);
+    fht_exchange<EPL, 2>(v, lane);
+    fht_exchange<EPL, 4>(v, lane);
+    fht_exchange<EPL, 8>(v, lane);
+    fht_exchange<EPL, 16>(v, lane);
+    fht_exchange<EPL, 32>(v, lane);
     if (EPL >= 4) {
 #pragma unroll
         for (int k = 0; k < EPL; k += 4)

@@ -403,15 +403,15 @@ struct RegHeap : HeapOps {
 //
 // The reference's loop over the batch is, with U_j = run + candidates accepted before j and t_j = k-th smallest of U_j
 // (+inf while |U_j| < k):   skip j if lb_j >= t_j;  drop j if d_j is not finite;  accept j iff d_j < t_j (then the
-// maximum leaves when |U| > k).  Its final top-k F is the k smallest of run + A (A = accepted candidates), t_end = max F.
-// Claim: F = the k smallest of  run + ALL finite candidates of the batch  (F'), provided every candidate o with
-// lb_o >= d_o ("odd": lower bound not below the refined distance) that is in F' has lb_o < max F'.
-// Proof: thresholds only shrink, and the world W' that accepts everything has the smallest ones: t_j >= t'_j >= max F'.
-// (1) a member s of F' that is not odd: d_s <= max F' <= t_s and lb_s < d_s, so the reference evaluates and accepts it
-// (d_s == t_s is a tie, see below); an odd member: lb_o < max F' <= t_o by the proviso, same conclusion.  So F' is inside
-// run + A.  (2) a candidate outside A was skipped (d > lb >= t_j, or odd and then outside F' by (1)... else the proviso
-// fails) or rejected (d > t_j): it is >= t_j >= t_end, so leaving it out or putting it in does not change the k
-// smallest.  Hence F = F'.  No acceptance decision, no thresholds — one merge:
+// maximum leaves when |U| > k).  Its final top-k F is the k smallest of run + A (A = accepted candidates).
+// Claim: F = F' := the k smallest of  run + C,  C = ALL finite candidates of the batch, provided every candidate o in F'
+// with lb_o >= d_o ("odd": lower bound not below the refined distance) has lb_o < m' := max F'.
+// Proof (|run + C| >= k; otherwise every threshold is +inf, nothing is skipped, rejected or evicted, and F = F' = all):
+// U_j is a subset of run + C, so its k-th smallest is not below that of run + C:  t_j >= m'  for every j.  Take a
+// candidate s in F': d_s <= m' <= t_s.  If s is not odd, lb_s < d_s <= t_s: the reference evaluates it; if it is odd,
+// lb_s < m' <= t_s by the proviso: evaluated as well.  It then accepts s unless d_s == t_s — an equal key inside
+// run + C, reported as a tie (below).  So F' is a subset of run + A, which is a subset of run + C; being the k smallest of
+// the larger set, F' is also the k smallest of run + A, i.e. F.  No acceptance decision, no thresholds — one merge:
 //     G(u) = #{elements of run + candidates above u}:  run entries: position from the top + #{candidates > u};
 //     candidates: #{run entries > x} + #{candidates > x};  with E = max(0, |run| + |candidates| - k), u stays iff
 //     G(u) >= E, and its new position from the top is G(u) - E.  One scatter through LDS.
