@@ -94,8 +94,10 @@ hipError_t launch_select_rm(const SelectParams& p, uint32_t cap2, int row_in_lds
 
 hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) {
     const uint32_t cap2 = next_pow2(2 * p.nprobe) < 64u ? 64u : next_pow2(2 * p.nprobe);
-    const int row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536) ? 1 : 0; // <= 4096: registers
-    size_t lds = (size_t)cap2 * 8 + (size_t)p.D * 4 + kThreads * 4 + (row_in_lds ? (size_t)p.nlist * 4 : 0);
+    const size_t lds0 = (size_t)cap2 * 8 + (size_t)p.D * 4 + kThreads * 4;
+    // <= 4096 lists: the score row lives in registers; else in LDS while it fits beside the shortlist window
+    const int row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536 && lds0 + (size_t)p.nlist * 4 <= kLdsPerWorkgroupMax) ? 1 : 0;
+    size_t lds = lds0 + (row_in_lds ? (size_t)p.nlist * 4 : 0);
     const int stage = lds + (size_t)p.nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
     if (stage) lds += (size_t)p.nprobe * 16;
     if (p.nlist <= 4096) return launch_select_rm<2>(p, cap2, row_in_lds, lds, stage, device, s);

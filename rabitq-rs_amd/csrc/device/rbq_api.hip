@@ -898,7 +898,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     const uint32_t nlist = (uint32_t)ix->n_lists;
     uint32_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
     if (nprobe > nlist) nprobe = nlist;
-    if (nprobe > 4096) return fail(RBQ_INVALID_CONFIG, "nprobe > 4096 is not supported by the GPU probe selector");
+    if (nprobe > kNprobeMax) return fail(RBQ_INVALID_CONFIG, "nprobe > 8192 is not supported by the GPU probe selector (its shortlist lives in the LDS of one compute unit)");
     if (top_k > kTopKMax || scan_lds_bytes(Dc, D, ix->ex_bits, top_k) > kLdsPerWorkgroupMax)
         return fail(RBQ_INVALID_CONFIG, "top_k > 16384 is not supported by the GPU top-k stage (the exact heap lives in the LDS of one compute unit)");
     if (ix->rerank && top_k > 1024) return fail(RBQ_INVALID_CONFIG, "rerank supports top_k <= 1024");

@@ -106,6 +106,7 @@ constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
 constexpr int kQueueCap = kTileBlocks - 1 + kWindow <= 512 ? 512 : 1024; // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
+constexpr uint32_t kNprobeMax = 8192;             // largest nprobe after the clamp to n_lists (k_select_mfma: 2 x nprobe u64 keys in LDS)
 constexpr uint32_t kTopKMax = 16384;              // largest top_k at all: above kTopKRegMax the exact heap is an LDS array of top_k + 1 entries
 constexpr size_t kLdsPerWorkgroupMax = 160 * 1024; // LDS of one compute unit (gfx950)
 

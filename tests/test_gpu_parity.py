@@ -497,6 +497,29 @@ def test_gpu_matches_committed_vectors():
         idx.close()
 
 
+@pytest.mark.parametrize("nprobe", [4096, 5000, 8192])
+def test_nprobe_up_to_the_limit(nprobe):
+    """Thousands of probes per query (the reference clamps nprobe to n_lists and nothing else): the shortlist window of
+    k_select_mfma grows to 16 384 keys; 8193 is RBQ_INVALID_CONFIG."""
+    import torch
+    nlist, dim = 9000, 64
+    n = 3 * nlist
+    data = make_dataset(n, dim, 64, 65)
+    rng = np.random.default_rng(66)
+    cent = data[rng.choice(n, nlist, replace=False)].copy()
+    x, c = torch.from_numpy(data).cuda(), torch.from_numpy(cent).cuda()
+    assign = torch.cdist(x, c).argmin(dim=1).cpu().numpy().astype(np.uint32)
+    built = rq.builder.train_with_clusters(data, cent, assign, 7, 0, 1, 67, True)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(6, dim, 64, 68)
+    _compare(built, idx, q, 10, nprobe)
+    if nprobe == 8192:
+        with pytest.raises(rq.RabitqError) as e:
+            idx.batch_search_raw(q, rq.SearchParams(10, 8193))
+        assert e.value.kind == "InvalidConfig" and "8192" in e.value.detail
+    idx.close()
+
+
 @pytest.mark.parametrize("nprobe", [300, 600, 800])
 def test_large_nprobe_select_paths(nprobe):
     """nprobe > 256: more than one probe per selector thread, 1024/2048-entry shortlist windows (bitonic sort
