@@ -575,7 +575,7 @@ def main():
 
             timed(pageable, 1, 3, 1)
             timed(pinned, 1, 3, 1)
-            reps = max(8, min(40, a.steps) * a.batch // per_call)
+            reps = max(10, 64 * a.batch // per_call)  # calls per thread and try (a few tens of ms: thread start-up does not weigh)
             want = ids_all[:kb].reshape(per_call, a.top_k)
             leg = {"queries_per_call": per_call,
                    "queries_per_s_1_caller_thread": timed(pageable, 1, reps),
