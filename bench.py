@@ -184,7 +184,7 @@ class TopkExchange:
     packed buffer per stream, so the final top-k exchange is a single all_gather per batch.  Used by the timed loop on
     HBM buffers over RCCL and by tests/test_dist_gloo.py on CPU buffers over gloo."""
 
-    def __init__(self, torch, dev, batch, top_k, nstreams, world, gather):
+    def __init__(self, torch, dev, batch, top_k, nstreams, world, gather, single_rank_group=False):
         self.torch, self.batch, self.top_k, self.world = torch, batch, top_k, world
         nres = batch * top_k
         self.pack = [torch.empty(nres * 12, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
@@ -192,7 +192,7 @@ class TopkExchange:
         self.scores = [p[nres * 8:].view(torch.float32).view(batch, top_k) for p in self.pack]
         self.counts = [torch.empty(batch, dtype=torch.int32, device=dev) for _ in range(nstreams)]
         # gather targets: one set per stream, so overlapping batches never share a buffer
-        self.gathered = [[torch.empty_like(self.pack[0]) for _ in range(world)] for _ in range(nstreams)] if (gather and world > 1) else None
+        self.gathered = [[torch.empty_like(self.pack[0]) for _ in range(world)] for _ in range(nstreams)] if (gather and (world > 1 or single_rank_group)) else None
 
     def gather(self, dist, s):
         """all_gather of stream s's packed results (enqueue it on the stream the search ran on)"""
@@ -247,7 +247,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # RBQ_BENCH_FORCE_DIST: a process group even for ONE rank — the N > 1 code (RCCL init, the per-batch all_gather on the
+    # batch's stream, barrier, all_reduce) then runs on a one-GPU box too (tests/test_gpu_parity.py)
+    use_dist = world > 1 or bool(os.environ.get("RBQ_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if os.environ.get("RBQ_BENCH_REHEARSAL"):
             dist.init_process_group("gloo")
@@ -396,7 +399,7 @@ def main():
         """`steps` timed steps after `warmup`, batches qb[NB'] rotating, on ns streams; returns (seconds, profile)"""
         nbq = qb.shape[0]
         streams = [torch.cuda.Stream(dev) for _ in range(ns)]
-        ex = TopkExchange(torch, dev, a.batch, a.top_k, ns, world, gather)
+        ex = TopkExchange(torch, dev, a.batch, a.top_k, ns, world, gather, single_rank_group=use_dist)
         d_ids, d_sc, d_cnt = ex.ids, ex.scores, ex.counts
         counter = [0]
 
@@ -411,7 +414,7 @@ def main():
                     ex.gather(dist, s)
 
         def fence():
-            if gather and world > 1:
+            if gather and use_dist:
                 dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -473,7 +476,7 @@ def main():
 
     ns = max(1, a.streams)
     dt, prof = run_timed(idx, q_all, a.nprobe, a.steps, a.warmup, ns, gather=True)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -525,7 +528,7 @@ def main():
             sm = {s: idx.profile_stage(s) for s in ("prep", "rank", "select", "scan")}
             serial = {"stage_ms": {k: round(v[0], 4) for k, v in sm.items()}, "launches": sm["scan"][1]}
             idx.release_stream(stv.cuda_stream)
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     # the host-buffer entry point (rbq_search_batch: H2D of the queries, the four kernels, D2H of the results) — what a
@@ -737,7 +740,7 @@ def main():
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()  # rank 0 has extra (supplementary) work behind it: nobody tears the group down early
         dist.destroy_process_group()
 

@@ -611,6 +611,29 @@ def test_bench_two_rank_rehearsal():
     assert 0.0 <= d["pruned"]["block_skip_frac"] < 1.0 and d["recall_at_10"] > 0.9
 
 
+def test_bench_rccl_single_rank_group():
+    """The RCCL calls of bench.py's N > 1 path — init_process_group("nccl", device_id), one all_gather per batch enqueued on
+    the batch's own stream (six streams in flight), barrier, all_reduce, teardown — executed for real on this one-GPU box with
+    a one-rank communicator (RCCL refuses two ranks on one device: that is what the gloo rehearsal above is for)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RBQ_BENCH_FORCE_DIST="1")
+    env.pop("RBQ_BENCH_REHEARSAL", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "1", "--steps", "12", "--warmup", "2", "--no-extras", "--no-cpu", "--nbatches", "4"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["pruned"]["launches"] == 12 and d["recall_at_10"] > 0.9
+    assert d["roofline"]["ids_identical_to_product_configuration"]
+
+
 def test_library_first_then_torch_in_a_fresh_process():
     """A fresh Python process that searches through librbq.so BEFORE it ever imports torch must still find the GPU
     from torch afterwards (one HIP runtime per process: rabitq_rs_amd.index._hip_runtime_of_torch_first).  This
