@@ -612,9 +612,9 @@ def test_bench_two_rank_rehearsal():
 
 
 def test_bench_rccl_single_rank_group():
-    """The RCCL calls of bench.py's N > 1 path — init_process_group("nccl", device_id), one all_gather per batch enqueued on
-    the batch's own stream (six streams in flight), barrier, all_reduce, teardown — executed for real on this one-GPU box with
-    a one-rank communicator (RCCL refuses two ranks on one device: that is what the gloo rehearsal above is for)."""
+    """The RCCL calls of bench.py's N > 1 path — init_process_group("nccl", device_id), one all_gather per bucket of batches on
+    the exchange stream behind the six search streams, barrier, all_reduce, teardown — executed for real on this one-GPU box
+    with a one-rank communicator (RCCL refuses two ranks on one device: that is what the gloo rehearsal above is for)."""
     import json
     import os
     import socket
