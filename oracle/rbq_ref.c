@@ -632,6 +632,26 @@ static int cmp_i64(const void* a, const void* b) {
     return (x > y) - (x < y);
 }
 
+/* after the call a[k] is the k-th smallest, everything before it is smaller, everything after it larger (quickselect with a
+ * median-of-three pivot on distinct keys) */
+static void select_nth_i64(int64_t* a, size_t n, size_t k) {
+    size_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        int64_t x = a[lo], y = a[mid], z = a[hi];
+        const int64_t pivot = x < y ? (y < z ? y : (x < z ? z : x)) : (x < z ? x : (y < z ? z : y));
+        size_t i = lo, j = hi;
+        while (i <= j) {
+            while (a[i] < pivot) ++i;
+            while (a[j] > pivot) --j;
+            if (i <= j) { const int64_t t = a[i]; a[i] = a[j]; a[j] = t; ++i; if (j == 0) break; --j; }
+        }
+        if (k <= j) hi = j;
+        else if (k >= i) lo = i;
+        else return;
+    }
+}
+
 /* returns nprobe list ids in probe order */
 size_t ref_select_probes(const rbq_header* h, const rbq_list_view* lists, const float* rq,
                          uint32_t nprobe_in, uint32_t* out_cids) {
@@ -646,7 +666,10 @@ size_t ref_select_probes(const rbq_header* h, const rbq_list_view* lists, const 
     }
     size_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
     if (nprobe > nl) nprobe = nl;
-    qsort(keys, nl, sizeof(int64_t), cmp_i64);
+    /* select_nth_unstable_by(nprobe - 1) then sort of the first nprobe (src/ivf.rs:1808-1823): the keys are distinct (the
+     * list id is part of them), so the order is the full sort's */
+    if (nprobe < nl) select_nth_i64(keys, nl, nprobe - 1);
+    qsort(keys, nprobe, sizeof(int64_t), cmp_i64);
     for (size_t i = 0; i < nprobe; ++i) out_cids[i] = (uint32_t)(keys[i] & 0xffffffff);
     free(keys);
     return nprobe;

@@ -323,3 +323,30 @@ def test_oracle_matches_committed_vectors():
         for k, v in got.items():
             w = want[f"{name}/{k}"]
             assert v.shape == w.shape and np.array_equal(v.view(np.uint8), w.view(np.uint8)), f"{name}/{k}"
+
+
+def test_probe_selection_is_the_full_sort_prefix():
+    """ref_select_probes selects with a quickselect + sort of the prefix like the reference (select_nth_unstable_by + sort,
+    src/ivf.rs:1808-1823); with the list id in the key the result is the prefix of the full (score, cid) sort — checked here
+    against numpy on the canonical scores, L2 and IP, nprobe values incl. both clamps.  (Large list counts: the GPU parity tests
+    with 5000 / 9000 / 17 000 / 65 536 lists compare the device's independent selection with it.)"""
+    rng = np.random.default_rng(4711)
+    for metric in (0, 1):
+        data, built = build_index(n=900, dim=64, nlist=37, total_bits=3, seed=91, metric=metric)
+        hdr = built.hdr
+        D = hdr.padded_dim
+        q = make_dataset(5, 64, 3, 92)
+        for qi in range(5):
+            rq = oracle.rotate(built, q[qi])
+            cents = np.stack([built.centroid(c) for c in range(37)])
+            rq = np.ascontiguousarray(rq, np.float32)
+            if metric == 0:
+                sc = np.array([L().ref_l2_distance_sqr(rq.ctypes.data, cents[c].ctypes.data, D) for c in range(37)], np.float32)
+                order = np.lexsort((np.arange(37), sc))
+            else:
+                sc = np.array([L().ref_dot(rq.ctypes.data, cents[c].ctypes.data, D) for c in range(37)], np.float32)
+                order = np.lexsort((np.arange(37), -sc))
+            for nprobe in (0, 1, 2, 7, 36, 37, 50):
+                got = oracle.select_probes(built, rq, nprobe)
+                want = order[:min(max(nprobe, 1), 37)]
+                assert np.array_equal(got, want.astype(np.uint32)), (metric, qi, nprobe)
