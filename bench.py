@@ -45,6 +45,17 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 HEADLINE = dict(n=1_000_000, dim=960, nlist=4096, nprobe=128, bits=7, metric=0, batch=1024, top_k=10)
+# BASELINE.json `configs` by name; cfg3 = the headline; the reference's own benchmark setting is top_k = 100
+# (examples/recall_qps_sweep.rs:111,120,225-237)
+PRESETS = {
+    "cfg2": dict(n=1_000_000, dim=128, nlist=1024, nprobe=64, bits=7, metric=0, batch=1024, top_k=10),
+    "cfg3": dict(HEADLINE),
+    "cfg3_b4096": dict(HEADLINE, batch=4096, nbatches=8),
+    "cfg4": dict(n=1_000_000, dim=960, nlist=4096, nprobe=256, bits=3, metric=1, batch=1024, top_k=10),
+    "top100": dict(HEADLINE, top_k=100),
+    "cfg5": dict(n=100_000_000, dim=768, nlist=65536, nprobe=512, bits=7, metric=0, batch=16384, top_k=10, nbatches=2,
+                 stream_build=2_000_000, steps=8, warmup=2, streams=4),
+}
 
 
 def parse():
@@ -75,7 +86,24 @@ def parse():
     ap.add_argument("--kmeans-iters", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], help="rbq_debug_set_option name=value (diagnostic A/B runs)")
     ap.add_argument("--streams", type=int, default=6, help="HIP streams the batches are issued on, round-robin (tools/streams_sweep.py)")
-    return ap.parse_args()
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS),
+                    help="a BASELINE.json configuration by name (sets n/dim/nlist/nprobe/bits/metric/batch/top-k; explicit flags win)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the K-step timed region is repeated (each repeat bracketed by barrier + synchronize) until this much "
+                         "time has been measured; value = median region (0 = one region)")
+    ap.add_argument("--in-library", action="store_true",
+                    help="ONE process, ONE handle with --gpus replicas, host buffers through rbq_search_batch (the reference's "
+                         "batch_search binding, src/ivf.rs:1743-1752) instead of one process per GPU")
+    ap.add_argument("--caller-threads", type=int, default=1, help="--in-library: host threads calling rbq_search_batch concurrently")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency leg")
+    argv = json.loads(os.environ["RBQ_BENCH_ARGV"]) if (os.environ.get("RBQ_BENCH_ARGV") and len(sys.argv) == 1) else sys.argv[1:]
+    a = ap.parse_args(argv)
+    if a.config:
+        given = {w.split("=")[0] for w in argv if w.startswith("--")}
+        for k, v in PRESETS[a.config].items():
+            if "--" + k.replace("_", "-") not in given:
+                setattr(a, k, v)
+    return a
 
 
 INTRINSIC_DIM = 32  # GIST-like: neighbours live on a low-dimensional manifold, not an isotropic ball
@@ -235,8 +263,30 @@ def traffic_of(c, D, Dc, ex_bits, launches):
     return tot / L, {k: v / L for k, v in b.items()}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a CHILD process and relay its
+    JSON line and exit code.  Nothing in this (parent) process has touched the GPU: torch.cuda and librbq are imported
+    further down, never here, and the child is a new process, not an exec of one that initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the ranks read their arguments from the environment: torch.distributed.run's own parser would try to match bench
+    # flags such as --n against its options (ambiguous prefix) if they followed the script on its command line
+    env["RBQ_BENCH_ARGV"] = json.dumps(sys.argv[1:])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)]
+    print(f"[bench] --gpus {a.gpus}: launching {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode  # stdout is inherited: rank 0's JSON line goes straight through
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and not a.in_library and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     import rabitq_rs_amd as rq
@@ -246,8 +296,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("RBQ_BENCH_REHEARSAL"):  # several ranks on ONE GPU with gloo: exercises the N>1 control flow only
         local = 0
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if a.gpus > 1 and not a.in_library and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} under torch.distributed.run needs nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if a.in_library and world != 1:
+        raise SystemExit("--in-library is ONE process with --gpus replicas inside one handle: do not start it under torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -262,6 +314,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    lib_devs = None
+    if a.in_library:
+        lib_devs = [0] * a.gpus if os.environ.get("RBQ_BENCH_REHEARSAL") else list(range(a.gpus))
+        a.nbatches = max(a.nbatches, 2 * a.gpus)
+        if a.device_build and not a.stream_build:
+            a.stream_build = a.n  # the streamed builder is the device encoder that replicates (one chunk = the whole set)
     if world > 1 and not a.stream_build:
         a.device_build = True  # N ranks x an all-core CPU build on one host would only oversubscribe it; the
                                # device encoder produces the identical index (tests/test_gpu_parity.py)
@@ -331,7 +389,7 @@ def main():
             del xc
             if c % 8 == 0:
                 progress(f"pass 2: chunk {c + 1}/{nch} pushed")
-        idx = sb.finish()
+        idx = sb.finish(devices=lib_devs)
         t_enc_only = time.time() - t0 - t_gen
         del assigns
         progress(f"streamed encode done in {t_enc_only:.2f} s (+ {t_gen:.2f} s regenerating the chunks)")
@@ -360,7 +418,7 @@ def main():
             built = rq.builder.train_with_clusters(x_host, cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits,
                                                    a.metric, rq.RotatorType.FhtKacRotator, 20260104, True)
             t_up0 = time.time()
-            idx = rq.IvfRabitqIndex.from_built(built, device=local)
+            idx = rq.IvfRabitqIndex.from_built(built, device=local) if lib_devs is None else rq.IvfRabitqIndex.from_built(built, devices=lib_devs)
             t_upload = time.time() - t_up0
             del x_host
         gt = exact_topk(torch, x, q_flat, a.top_k, a.metric)
@@ -400,8 +458,11 @@ def main():
     Dc = (D + 63) // 64 * 64
     ex_bits = a.bits - 1
 
-    def run_timed(index, qb, nprobe, steps, warmup, ns, gather):
-        """`steps` timed steps after `warmup`, batches qb[NB'] rotating, on ns streams; returns (seconds, profile)"""
+    def run_timed(index, qb, nprobe, steps, warmup, ns, gather, min_seconds=0.0):
+        """Timed regions of exactly `steps` steps each (after `warmup` untimed steps), batches qb[NB'] rotating, on ns streams.
+        Every region is bracketed by barrier + synchronize on both sides; regions repeat until `min_seconds` have been
+        measured (a 20-step region lasts 4 ms: one sample of it is mostly noise).  Returns (region seconds — max over ranks —,
+        this rank's own region seconds, profile over all regions)."""
         nbq = qb.shape[0]
         streams = [torch.cuda.Stream(dev) for _ in range(ns)]
         # Results go to 2 * ns slots = two buckets of ns consecutive batches.  A bucket is gathered by ONE all_gather (ns x
@@ -454,23 +515,34 @@ def main():
             step()
         fence()
         # HIP events on the kernels' own stream, no host sync inside the timed region.  Only the roofline kernel is
-        # timed here (the event pair rides on the dispatch packet); about 25 launches are sampled.  The traffic
+        # timed here (the event pair rides on the dispatch packet); about 25 launches per region are sampled.  The traffic
         # counters run on every launch (one atomicAdd per workgroup at exit).
         index.profile_begin(stages=("scan",), every=int(os.environ.get("RBQ_BENCH_TAP_EVERY", str(max(1, steps // 25)))))
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        t_issue = time.perf_counter() - t0  # host time to enqueue the region's work (no wait in it)
-        fence()
-        dt = time.perf_counter() - t0
+        dts, own, t_issue = [], [], 0.0
+        while True:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            t_issue += time.perf_counter() - t0  # host time to enqueue the region's work (no wait in it)
+            fence()
+            dt = time.perf_counter() - t0
+            own.append(dt)
+            if gather and use_dist:  # max over ranks (outside the timed bracket); identical on every rank afterwards
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            dts.append(dt)
+            if sum(dts) >= min_seconds or len(dts) >= 64:
+                break
         index.profile_end()
+        nreg = len(dts)
         ms, launches = index.profile_stage("scan")
-        prof = {"issue_s": t_issue, "scan_ms": ms, "scan_launches": launches, "scan_samples_ms": [round(float(v), 4) for v in index.profile_stage_samples("scan")],
-                "counters": index.profile_counters(),
+        prof = {"issue_s": t_issue / nreg, "scan_ms": ms, "scan_launches": launches, "scan_samples_ms": [round(float(v), 4) for v in index.profile_stage_samples("scan")][:64],
+                "counters": index.profile_counters(), "steps_total": steps * nreg,
                 "algorithmic_bytes": index.profile_scan_bytes()}
         for st in streams:
             index.release_stream(st.cuda_stream)
-        return dt, prof
+        return dts, own, prof
 
     def search_ids(index, qb, nprobe):
         """ids [nb][batch][top_k] of the given batches (one stream, synchronous)"""
@@ -503,19 +575,142 @@ def main():
                         "and rotated query); provably pruned blocks are never fetched, so the algorithmic bytes are NOT moved "
                         "and algorithmic_over_time is not a bandwidth"}
 
+    def pinned_sets(per_call, nsets, nthr=1):
+        """page-locked (rbq_host_alloc) query / ids / scores / counts buffers, one set per (thread, query set)"""
+        import ctypes as C
+        lib = rq.index.lib()
+        nbytes = [per_call * a.dim * 4, per_call * a.top_k * 8, per_call * a.top_k * 4, per_call * 4]
+        pin = [[[lib.rbq_host_alloc(b) for b in nbytes] for _ in range(nsets)] for _ in range(nthr)]
+        for j in range(nsets):
+            off = (j * per_call) % max(NB * a.batch - per_call + 1, 1)
+            qh = q_flat[off:off + per_call].cpu().numpy()
+            for t in range(nthr):
+                C.memmove(pin[t][j][0], qh.ctypes.data, nbytes[0])
+        return pin, nbytes
+
+    def free_sets(pin):
+        lib = rq.index.lib()
+        for a_ in pin:
+            for b_ in a_:
+                for p_ in b_:
+                    lib.rbq_host_free(p_)
+
+    def latency_leg():
+        """p50 / p99 of ONE rbq_search_batch call (page-locked host buffers in and out) at small nq — `search` (nq = 1,
+        src/ivf.rs:1705-1711) is the reference's primary API and what its published numbers time in a sequential loop
+        (examples/recall_qps_sweep.rs:127-138)."""
+        lib = rq.index.lib()
+        res = {}
+        for nq_ in (1, 8, 64, 256):
+            if nq_ > NB * a.batch:
+                continue
+            nsets = 16 if nq_ <= 64 else 8
+            pin, _ = pinned_sets(nq_, nsets)
+            call = lambda j: lib.rbq_search_batch(idx._h, pin[0][j][0], nq_, a.dim, a.top_k, a.nprobe, None, 0, pin[0][j][1], pin[0][j][2], pin[0][j][3], None)  # noqa: E731
+            for j in range(nsets):
+                assert call(j) == 0
+            reps = 200 if nq_ <= 64 else 100
+            ts = []
+            for r in range(reps):
+                t0 = time.perf_counter()
+                rc = call(r % nsets)
+                ts.append(time.perf_counter() - t0)
+                assert rc == 0
+            ts = np.array(ts) * 1e6
+            res[str(nq_)] = {"p50_us": round(float(np.percentile(ts, 50)), 1), "p99_us": round(float(np.percentile(ts, 99)), 1),
+                             "mean_us": round(float(ts.mean()), 1), "queries_per_s_sequential_calls": nq_ / (float(ts.mean()) * 1e-6), "calls": reps}
+            free_sets(pin)
+        res["note"] = ("one caller thread, one call at a time, distinct queries per call, page-locked buffers (rbq_host_alloc); "
+                       "includes H2D of the queries, the four kernels and the results written to host memory. Context only: the "
+                       "reference publishes sequential single-query numbers on its own hardware "
+                       "(benchmarks/gist_1m_results/recall_qps_fixed.csv)")
+        return res
+
+    if a.in_library:
+        # ---- ONE process, ONE handle with a.gpus replicas: a step = one rbq_search_batch call over gpus x batch queries in
+        # page-locked host buffers (weak scaling: `batch` queries per replica and step), results into host buffers
+        import ctypes as C
+        import threading
+        lib = rq.index.lib()
+        per_call = a.batch * a.gpus
+        nthr = max(1, a.caller_threads)
+        nsets = max(2, min(8, NB * a.batch // per_call))
+        pin, nbytes = pinned_sets(per_call, nsets, nthr)
+
+        def worker(t, n):
+            for r in range(n):
+                pp = pin[t][(t + r) % nsets]
+                rc_ = lib.rbq_search_batch(idx._h, pp[0], per_call, a.dim, a.top_k, a.nprobe, None, 0, pp[1], pp[2], pp[3], None)
+                assert rc_ == 0, rc_
+
+        def region(n):
+            share = [n // nthr + (1 if t < n % nthr else 0) for t in range(nthr)]
+            th = [threading.Thread(target=worker, args=(t, share[t])) for t in range(1, nthr)]
+            t0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            worker(0, share[0])
+            for t_ in th:
+                t_.join()
+            return time.perf_counter() - t0
+
+        region(max(a.warmup, 2 * nthr))
+        dts = []
+        while True:
+            dts.append(region(a.steps))
+            if sum(dts) >= a.min_seconds or len(dts) >= 64:
+                break
+        dt = statistics.median(dts)
+        value = per_call * a.steps / dt
+        # results of the first query set against the exact ground truth, and against ONE replica serving the same queries
+        ids0 = np.ctypeslib.as_array(C.cast(pin[0][0][1], C.POINTER(C.c_uint64)), shape=(per_call, a.top_k)).copy()
+        gtn = gt.cpu().numpy()[:per_call]
+        recall = recall_of(ids0, gtn, a.top_k)
+        d_i = torch.empty(per_call, a.top_k, dtype=torch.int64, device=dev)
+        d_s = torch.empty(per_call, a.top_k, dtype=torch.float32, device=dev)
+        d_c = torch.empty(per_call, dtype=torch.int32, device=dev)
+        idx.search_batch_device(q_flat[:per_call].contiguous().data_ptr(), per_call, a.dim, a.top_k, a.nprobe, d_i.data_ptr(), d_s.data_ptr(),
+                                d_c.data_ptr(), stream=None)
+        torch.cuda.synchronize(dev)
+        same = bool(np.array_equal(d_i.cpu().numpy().view(np.uint64), ids0))
+        what = f"N={a.n} d={a.dim}, nlist={a.nlist}, {a.bits}-bit, FhtKacRotator, {'L2' if a.metric == 0 else 'IP'}, nprobe={a.nprobe}, " \
+               f"top_k={a.top_k}, batch={a.batch} per GPU"
+        out = {"metric": f"queries/sec at recall@{a.top_k}={recall:.3f}, in-library replicas, host buffers, synthetic {a.dataset} {what}",
+               "value": value, "unit": "queries/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": f"synthetic GIST-1M-shaped fvecs ({a.dataset}) {what}",
+                          "parallelism": f"in-library: ONE process, ONE rbq_index with {a.gpus} replicas on devices {lib_devs}; every step is one "
+                                         f"rbq_search_batch call over {per_call} queries in page-locked host buffers, sharded over the replicas",
+                          "caller_threads": nthr, "distinct_query_sets": nsets, "timed_regions": len(dts),
+                          "value_is": "host-buffer rate (H2D of the queries and results in host memory included)"},
+               "region_ms": [round(v * 1e3, 3) for v in dts],
+               f"recall_at_{a.top_k}": recall, "recall_ok": recall >= 0.95,
+               "ids_identical_to_one_replica_device_entry": same,
+               "replicas": int(idx.device_count()), "rank_fallbacks": int(idx.rank_fallbacks()), "heap_restarts": int(idx.heap_restarts()),
+               "latency": None if a.no_latency else latency_leg(),
+               "roofline": None, "cpu_baseline": None}
+        free_sets(pin)
+        print(json.dumps(out))
+        return
+
     ns = max(1, a.streams)
-    dt, prof = run_timed(idx, q_all, a.nprobe, a.steps, a.warmup, ns, gather=True)
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dts, own_dts, prof = run_timed(idx, q_all, a.nprobe, a.steps, a.warmup, ns, gather=True, min_seconds=a.min_seconds)
+    dt = statistics.median(dts)  # the median K-step region (each one bracketed by barrier + synchronize, max over ranks)
     value = a.batch * world * a.steps / dt
+    per_rank = [a.batch * a.steps / statistics.median(own_dts)]
+    rccl_world = None
+    if use_dist:
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = per_rank[0]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.tolist()]
+        rccl_world = dist.get_world_size() if dist.get_backend() == "nccl" else None
 
     # results of every batch (one stream): recall over ALL of them, and the same ids whatever the stream
     ids_all = search_ids(idx, q_all, a.nprobe)
     gtn = gt.cpu().numpy().reshape(NB, a.batch, a.top_k)
     recall = recall_of(ids_all.reshape(-1, a.top_k), gtn.reshape(-1, a.top_k), a.top_k)
-    pruned = pruned_object(prof, a.steps)
+    pruned = pruned_object(prof, prof["steps_total"])
 
     # the roofline figure: the same kernel with the block-level bound switched off streams EVERY probed block — the
     # algorithmic bytes are really moved (results identical, only the work changes); one stream, k_scan alone on the chip
@@ -524,7 +719,7 @@ def main():
     if rank == 0:
         n_rf = max(6, min(a.steps // 4, 50))
         idx.set_option("block_bound", 0)
-        _, p2 = run_timed(idx, q_all, a.nprobe, n_rf, 2, 1, gather=False)
+        _, _, p2 = run_timed(idx, q_all, a.nprobe, n_rf, 2, 1, gather=False)
         ids_off = search_ids(idx, q_all[:2], a.nprobe)
         idx.set_option("block_bound", 1)
         alg2 = p2["algorithmic_bytes"] / n_rf
@@ -537,7 +732,7 @@ def main():
                     "configuration": "block-level bound OFF (rbq_debug_set_option block_bound=0): every probed block is streamed, "
                                      "so the algorithmic bytes (SURVEY 8d: sum n_c*(D/8+12)) are the bytes moved; one stream, "
                                      "distinct query batch per launch; HIP events carried by the dispatch packets",
-                    "note": "traffic (PMC) is collected in separate rocprofv3 passes: profiles/r2/; bytes_requested_per_launch is "
+                    "note": "traffic (PMC) is collected in separate rocprofv3 passes: profiles/r3/; bytes_requested_per_launch is "
                             "the kernel's own count for the same launches (codes + factor rows + stream + ex codes + LUT)"}
         if stage_pass:
             # every stage alone on one stream (no overlap between batches), rotating batches
@@ -636,6 +831,35 @@ def main():
                         "approach the device-resident rate.  `value` is the device-resident rate; these are the rates a host-side "
                         "caller sees.")
 
+    latency = latency_leg() if (rank == 0 and not a.no_latency and not a.ab) else None
+
+    # Self-check for indexes no CPU oracle run can cover (device-built: cfg5 at 100 M vectors): the first 256 queries again
+    # with every shortcut switched off — canonical all-pairs ranking instead of the MFMA shortlist, BinaryHeap emulation from
+    # the first candidate, no block-level bound — must give the same bits.
+    self_check = None
+    if rank == 0 and not a.ab:
+        nsc = min(256, a.batch)
+        qs_ = q_all[0][:nsc].contiguous()
+        def run_sc():
+            d_i = torch.empty(nsc, a.top_k, dtype=torch.int64, device=dev)
+            d_s = torch.empty(nsc, a.top_k, dtype=torch.float32, device=dev)
+            d_c = torch.empty(nsc, dtype=torch.int32, device=dev)
+            st_ = torch.cuda.Stream(dev)
+            idx.search_batch_device(qs_.data_ptr(), nsc, a.dim, a.top_k, a.nprobe, d_i.data_ptr(), d_s.data_ptr(), d_c.data_ptr(), stream=st_.cuda_stream)
+            st_.synchronize()
+            idx.release_stream(st_.cuda_stream)
+            return d_i.cpu().numpy(), d_s.cpu().numpy().view(np.uint32), d_c.cpu().numpy()
+        fast = run_sc()
+        for k_, v_ in (("exact_rank", 1), ("exact_heap", 1), ("block_bound", 0)):
+            idx.set_option(k_, v_)
+        slow = run_sc()
+        for k_, v_ in (("exact_rank", 0), ("exact_heap", 0), ("block_bound", 1)):
+            idx.set_option(k_, v_)
+        self_check = {"queries": nsc, "ids_identical": bool(np.array_equal(fast[0], slow[0])), "score_bits_identical": bool(np.array_equal(fast[1], slow[1])),
+                      "counts_identical": bool(np.array_equal(fast[2], slow[2])),
+                      "against": "the same queries with exact_rank=1 (canonical all-pairs centroid ranking), exact_heap=1 (BinaryHeap emulation from the "
+                                 "first candidate) and block_bound=0 (every probed block scanned)"}
+
     # second data set of the pair (rank 0, headline workload only): SURVEY 8d's isotropic mixture
     datasets = {a.dataset: {"recall_at_k": recall, "queries_per_s": value / world, "nprobe": a.nprobe,
                             "block_skip_frac": pruned["block_skip_frac"], "role": "headline"}}
@@ -655,7 +879,8 @@ def main():
         torch.cuda.empty_cache()
         rows, reached = [], None
         for npb in (a.nprobe, 2 * a.nprobe, 4 * a.nprobe):
-            dti, pi = run_timed(idx2, qi, npb, 24, 4, ns, gather=False)
+            dti, _, pi = run_timed(idx2, qi, npb, 24, 4, ns, gather=False)
+            dti = dti[0]
             ri = recall_of(search_ids(idx2, qi, npb).reshape(-1, a.top_k), gti, a.top_k)
             po = pruned_object(pi, 24)
             rows.append({"nprobe": npb, "recall_at_k": ri, "queries_per_s": a.batch * 24 / dti, "block_skip_frac": po["block_skip_frac"],
@@ -685,6 +910,10 @@ def main():
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3,
+        "timed_regions": len(dts),  # value = the MEDIAN region; every region = exactly `steps` steps between barrier + synchronize
+        "region_ms": [round(v * 1e3, 3) for v in dts],
+        "per_rank_queries_per_s": per_rank,  # every rank's own median region (no max over ranks)
+        "rccl_world_size": rccl_world,       # dist.get_world_size() of the nccl (= RCCL) group; null without one
         "host_issue_ms_per_step": prof["issue_s"] / a.steps * 1e3,  # host time to enqueue one step (launches + gather), rank 0
         "higher_is_better": True,
         "scaling": "weak",
@@ -706,6 +935,8 @@ def main():
         "roofline": roofline,
         "pruned": pruned,
         "pcie_inclusive": pcie,
+        "latency": latency,
+        "self_check": self_check,
         "datasets": datasets,
     }
 
@@ -724,21 +955,25 @@ def main():
         except (OSError, ValueError):
             pass
         omp_max = oracle.lib().ref_num_threads()
-        cand = sorted({c for c in (quota, 8, 16, 32, 64, avail, omp_max) if c and c <= max(avail, omp_max)})
+        cand = sorted({c for c in (quota, 8, 16, 32, avail, omp_max) if c and c <= max(avail, omp_max)})
         rc, oids, osc, ocnt, _ = oracle.search_batch(built, qh0, a.top_k, a.nprobe, nthreads=cand[0])  # warm-up pass + parity check
         sweep = {}
-        for c in cand:
-            t0 = time.perf_counter()
-            oracle.search_batch(built, qh0, a.top_k, a.nprobe, nthreads=c)
-            sweep[c] = a.batch / max(time.perf_counter() - t0, 1e-6)
-        cores = max(sweep, key=sweep.get)
+        for c in cand:  # informational: two passes per thread count, the better one
+            best = 0.0
+            for _ in range(2):
+                t0 = time.perf_counter()
+                oracle.search_batch(built, qh0, a.top_k, a.nprobe, nthreads=c)
+                best = max(best, a.batch / max(time.perf_counter() - t0, 1e-6))
+            sweep[c] = best
+        # the thread count IS the CPU share this job was given (cgroup quota); without a quota, the fastest of the sweep
+        cores = quota if (quota and quota in sweep) else max(sweep, key=sweep.get)
         pass_t = a.batch / sweep[cores]
         same = bool(np.array_equal(oids, ids_all[0]))
         same2 = None
         if NB > 1:  # a second batch of the rotation, so the check is not tied to batch 0
             rc2, oids2, _, _, _ = oracle.search_batch(built, q_all[NB - 1].cpu().numpy(), a.top_k, a.nprobe, nthreads=cores)
             same2 = bool(np.array_equal(oids2, ids_all[NB - 1]))
-        reps = int(max(1, min(50, round(a.cpu_seconds * 0.6 / 3 / pass_t))))
+        reps = int(max(2, min(100, round(a.cpu_seconds * 0.6 / 3 / pass_t))))
         rates = []
         for _ in range(3):  # median of 3 timed repeats
             t0 = time.perf_counter()
@@ -760,7 +995,7 @@ def main():
                                "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "cpus_in_affinity_mask": avail, "cgroup_cpu_quota": quota,
                                "thread_sweep_queries_per_s": {str(k): v for k, v in sweep.items()},
                                "sample": f"query batch 0 ({a.batch} queries) on the same index, one query per thread (OpenMP static = "
-                                         f"Rayon par_iter) on the fastest thread count of a short sweep, median of 3 timed repeats of {reps} passes after 1 warm-up pass",
+                                         f"Rayon par_iter), threads = the job's cgroup CPU quota (else the fastest of the sweep), median of 3 timed repeats of {reps} passes after warm-up passes",
                                "all_core_repeats": rates,
                                "single_thread": {"value": statistics.median(r1), "unit": "queries/s", "cores": 1, "repeats": r1,
                                                  "sample": f"first {ns1} queries of batch 0, sequential, median of 3"},

@@ -249,10 +249,10 @@ uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
  * re-run inside the scan kernel with the exact BinaryHeap emulation (src/ivf.rs:2078-2105 pushes into a
  * std BinaryHeap, whose tie behaviour depends on its layout). Diagnostic. */
 uint64_t rbq_debug_heap_restarts(const rbq_index* idx);
-/* Diagnostic: copy one of the index's device arrays ("blocks", "ids", "ex", "fadd_ex", "fres_ex", "bsum",
+/* Diagnostic: copy one of the index's device arrays ("blocks", "ids", "ex", "fadd_ex", "fres_ex", "bsum", "lsum", "bsumx",
  * "centroids", "list_gb0", "list_n") to the host; `bytes` must be the array's exact size. */
 int rbq_debug_copy_index(rbq_index* idx, const char* name, void* dst, uint64_t bytes);
-/* Diagnostic: copy an intermediate buffer ("rot", "lut", "consts", "scores", "probe", "nstream", "wl") of the
+/* Diagnostic: copy an intermediate buffer ("rot", "lut", "consts", "scores", "probe", "nstream", "wl", "nvec", "dead_skipped") of the
  * workspace that rbq_search_batch_device bound to `hip_stream`; the caller has synchronised that stream. */
 int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name, void* dst, uint64_t bytes);
 /* Diagnostic switches; results are identical under every setting, only the work done changes:
@@ -262,6 +262,9 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *   "f32_rank" 1         approximate list scores from the f32 MFMA GEMM instead of the split-bf16 one
  *   "wg_prep" 1          workgroup-per-query query preparation for every rotator (default: one wave per query)
  *   "exact_heap" 1       keep the top-k in the BinaryHeap emulation from the first candidate (no sorted fast path)
+ *   "lazy_select" 0      score and stream every probed list (default 1: lists that are provably skipped as a whole —
+ *                        every lower bound of the list at or above a select-time upper bound of the k-th distance — are
+ *                        neither scored exactly nor streamed; their sizes still count in skipped_by_lower_bound)
  * and two that are not result-neutral:
  *   "rerank" 0/1         the optional full-precision rerank (needs rbq_index_set_rerank_vectors)
  *   "debug_replica" r    which replica rbq_debug_copy_index / rbq_debug_copy_workspace read */

@@ -225,6 +225,19 @@ void ref_rotate(const rbq_header* h, const float* in, float* out) {
 static const int KPOS[16] = {3, 3, 2, 3, 1, 3, 2, 3, 0, 3, 2, 3, 1, 3, 2, 3};
 static const int KPERM0[16] = {0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15};
 
+/* Per-thread scratch reused across queries (slots never shrink): the timed CPU baseline then measures the search
+ * itself, not five malloc/free pairs per query. */
+static __thread void* g_scr[8];
+static __thread size_t g_scr_cap[8];
+static void* scratch(int slot, size_t bytes) {
+    if (bytes > g_scr_cap[slot]) {
+        free(g_scr[slot]);
+        g_scr[slot] = malloc(bytes ? bytes : 1);
+        g_scr_cap[slot] = g_scr[slot] ? bytes : 0;
+    }
+    return g_scr[slot];
+}
+
 void ref_pack_lut_f32(const float* q, size_t D, float* lut) {
     size_t ncb = D / 4;
     for (size_t i = 0; i < ncb; ++i) {
@@ -239,7 +252,7 @@ void ref_pack_lut_f32(const float* q, size_t D, float* lut) {
 
 void ref_query_lut(const float* q, size_t D, uint8_t* lut8, float* delta_out, float* sum_vl_out) {
     size_t T = D * 4;
-    float* lf = (float*)malloc(sizeof(float) * T);
+    float* lf = (float*)scratch(0, sizeof(float) * T);
     ref_pack_lut_f32(q, D, lf);
     float vl = lf[0], vr = lf[0];
     for (size_t i = 1; i < T; ++i) {
@@ -258,7 +271,6 @@ void ref_query_lut(const float* q, size_t D, uint8_t* lut8, float* delta_out, fl
     }
     *delta_out = delta;
     *sum_vl_out = vl * (float)(T / 16);
-    free(lf);
 }
 
 /* QueryPrecomputed::new, src/ivf.rs:862-878 */
@@ -656,7 +668,7 @@ static void select_nth_i64(int64_t* a, size_t n, size_t k) {
 size_t ref_select_probes(const rbq_header* h, const rbq_list_view* lists, const float* rq,
                          uint32_t nprobe_in, uint32_t* out_cids) {
     size_t nl = h->n_lists, D = h->padded_dim;
-    int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * nl);
+    int64_t* keys = (int64_t*)scratch(1, sizeof(int64_t) * nl);
     for (size_t c = 0; c < nl; ++c) {
         float s = h->metric == RBQ_METRIC_L2 ? ref_l2_distance_sqr(rq, lists[c].centroid, D)
                                              : ref_dot(rq, lists[c].centroid, D);
@@ -666,12 +678,12 @@ size_t ref_select_probes(const rbq_header* h, const rbq_list_view* lists, const 
     }
     size_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
     if (nprobe > nl) nprobe = nl;
-    /* select_nth_unstable_by(nprobe - 1) then sort of the first nprobe (src/ivf.rs:1808-1823): the keys are distinct (the
-     * list id is part of them), so the order is the full sort's */
+    /* select_nth_unstable_by(nprobe) (src/ivf.rs:1808: index nprobe, only when nprobe < len) then sort of the first nprobe
+     * (:1808-1823).  Selecting at index nprobe - 1 here leaves the same prefix SET, and the keys are distinct (the list id is
+     * part of them), so the sorted prefix is the full sort's either way. */
     if (nprobe < nl) select_nth_i64(keys, nl, nprobe - 1);
     qsort(keys, nprobe, sizeof(int64_t), cmp_i64);
     for (size_t i = 0; i < nprobe; ++i) out_cids[i] = (uint32_t)(keys[i] & 0xffffffff);
-    free(keys);
     return nprobe;
 }
 
@@ -700,9 +712,9 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
         if (out_scores) out_scores[i] = NAN;
     }
 
-    float* rq = (float*)malloc(sizeof(float) * D);
-    uint8_t* lut8 = (uint8_t*)malloc(D * 4);
-    uint32_t* cids = (uint32_t*)malloc(sizeof(uint32_t) * h->n_lists);
+    float* rq = (float*)scratch(2, sizeof(float) * D);
+    uint8_t* lut8 = (uint8_t*)scratch(3, D * 4);
+    uint32_t* cids = (uint32_t*)scratch(4, sizeof(uint32_t) * h->n_lists);
     ref_rotate(h, query, rq);
     ref_query_consts qc;
     ref_query_precompute(rq, D, h->ex_bits, &qc);
@@ -710,10 +722,10 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
     ref_query_lut(rq, D, lut8, &lut_delta, &lut_sum_vl);
     size_t nprobe = ref_select_probes(h, lists, rq, nprobe_in, cids);
 
-    if (top_k == 0) { free(rq); free(lut8); free(cids); return RBQ_OK; }
+    if (top_k == 0) return RBQ_OK;
 
     heap_t heap;
-    heap.d = (hent*)malloc(sizeof(hent) * ((size_t)top_k + 1));
+    heap.d = (hent*)scratch(5, sizeof(hent) * ((size_t)top_k + 1));
     heap.len = 0;
     size_t stride = D * 4 + 384, ex_bytes = D * h->ex_bits / 8;
 
@@ -774,7 +786,6 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
         if (out_scores) out_scores[i] = h->metric == RBQ_METRIC_L2 ? heap.d[i].distance : -heap.d[i].distance;
     }
     if (out_count) *out_count = (uint32_t)heap.len;
-    free(heap.d); free(rq); free(lut8); free(cids);
     return RBQ_OK;
 }
 

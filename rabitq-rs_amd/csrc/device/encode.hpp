@@ -295,6 +295,140 @@ __global__ __launch_bounds__(256) void k_block_summary(const uint8_t* __restrict
     }
 }
 
+// One workgroup per list (lazy probe selection, rank_mfma.hpp): BlockSummaryEx of every block and the factor ranges of
+// the WHOLE list (a BlockSummary over its blocks' summaries; an empty list gets an unusable one).
+//
+// BlockSummaryEx regroups the estimator around the list's centroid c.  With u' the centred total code of a vector
+// (u'_i = (bit_i << ex) + ex_i - (2^ex - 0.5), src/quantizer.rs) and ubar_i = bit_i - 0.5, for any rotated query q
+//   refined distance = f_add_ex + g_add + f_rescale_ex * <q, u'>    (src/ivf.rs:2086-2099; scale*ip + ex_dot + kbx = <q, u'>)
+//                    = [f_add_ex + f_rescale_ex * <c, u'>] + g_add + f_rescale_ex * <q - c, u'>
+//                   <=  S  + g_add + B * |q - c|,      S = f_add_ex + f_rescale_ex <c, u'>,  B = |f_rescale_ex| |u'|
+//   1-bit estimate  <=  S1 + g_add + B1 * |q - c|,     S1 = f_add + f_rescale <c, ubar>,     B1 = |f_rescale| sqrt(D) / 2
+// by Cauchy-Schwarz — against the ALL-codes range |q|_1 * 63.5 of block_lbmin this is 3-10x tighter, which is what makes
+// the select-time bound of the k-th distance (T_ub) useful.  <c, u'>, <c, ubar> and |u'|^2 are accumulated in f64 from
+// the device-layout codes; S, B, S1, B1 are rounded up.  |q - c| is the probed list's g_error (src/ivf.rs:1856).
+// 16 lanes per vector, lane l owns dims 16t + l (the layout of the ex codes, types.hpp).
+__global__ __launch_bounds__(256) void k_list_summaries(const uint8_t* __restrict__ blocks, const uint8_t* __restrict__ ex,
+                                                        const float* __restrict__ fadd_ex, const float* __restrict__ fres_ex,
+                                                        const float* __restrict__ cent, const BlockSummary* __restrict__ bsum,
+                                                        const uint32_t* __restrict__ list_gb0, const uint32_t* __restrict__ list_n,
+                                                        uint32_t D, uint32_t Dc, uint32_t ex_bits,
+                                                        BlockSummaryEx* __restrict__ bsumx, BlockSummary* __restrict__ lsum) {
+    extern __shared__ __align__(16) float s_cent[]; // [D]
+    __shared__ float sS[32], sB[32], sS1[32], sB1[32], sFa[32], sFr[32];
+    __shared__ uint32_t sBad[32];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, grp = tid >> 4, l = tid & 15u;
+    const uint32_t n = list_n[c], gb0 = list_gb0[c], nb = (n + 31u) >> 5;
+    for (uint32_t i = tid; i < D; i += 256) s_cent[i] = cent[(size_t)c * D + i];
+    __syncthreads();
+    const size_t stride = (size_t)Dc * 4 + 384, exd = ex_bytes_dev(D, ex_bits);
+    const uint32_t G16 = Dc >> 7, cpu = ex_cpu(ex_bits), nt = D / 16;
+    const double centre = (double)(1u << ex_bits) - 0.5;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t nv = (b + 1 == nb) ? n - b * 32u : 32u;
+        const uint8_t* blk = blocks + (size_t)(gb0 + b) * stride;
+        const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
+#pragma unroll 1
+        for (uint32_t half = 0; half < 2; ++half) {
+            const uint32_t v = grp + 16u * half;
+            if (v < nv) { // uniform per 16-lane group
+                const size_t slot = (size_t)(gb0 + b) * 32 + v;
+                const uint4* exu = reinterpret_cast<const uint4*>(ex + slot * exd) + l;
+                double dcu = 0.0, dcb = 0.0; // <c, u'>, <c, ubar>
+                uint32_t u2x4 = 0;          // sum (2 u'_i)^2: |u'|^2 * 4, exact in 32 bits (D <= 2048, |2u'| <= 127)
+                uint4 unit = make_uint4(0, 0, 0, 0);
+                for (uint32_t t = 0; t < nt; ++t) {
+                    const uint32_t i = 16u * t + l, col = i >> 3, g = col >> 4, cc = col & 15u;
+                    uint32_t word;
+                    if (g < G16) word = reinterpret_cast<const uint32_t*>(blk + (size_t)g * 512 + v * 16)[cc >> 2];
+                    else word = reinterpret_cast<const uint32_t*>(blk + (size_t)G16 * 512 + v * 8)[cc >> 2];
+                    const uint32_t bit = (word >> (8u * (cc & 3u) + 7u - (i & 7u))) & 1u;
+                    uint32_t code = 0;
+                    if (ex_bits) {
+                        const uint32_t k = t % cpu;
+                        if (k == 0) unit = exu[(t / cpu) * 16];
+                        const uint32_t pos = k * ex_bits, idx = pos >> 5, sh = pos & 31u;
+                        const uint32_t w0 = idx == 0 ? unit.x : idx == 1 ? unit.y : idx == 2 ? unit.z : unit.w;
+                        const uint32_t w1 = idx == 0 ? unit.y : idx == 1 ? unit.z : idx == 2 ? unit.w : 0u;
+                        uint32_t raw = w0 >> sh;
+                        if (sh + ex_bits > 32) raw |= w1 << (32 - sh);
+                        code = raw & ((1u << ex_bits) - 1u);
+                    }
+                    const double ci = (double)s_cent[i];
+                    const double up = (double)((bit << ex_bits) + code) - centre;
+                    dcu += ci * up;
+                    dcb += ci * ((double)bit - 0.5);
+                    const int tw = 2 * (int)((bit << ex_bits) + code) - (int)((2u << ex_bits) - 1u);
+                    u2x4 += (uint32_t)(tw * tw);
+                }
+#pragma unroll
+                for (int d = 8; d > 0; d >>= 1) {
+                    dcu += __shfl_xor(dcu, d, 16);
+                    dcb += __shfl_xor(dcb, d, 16);
+                    u2x4 += __shfl_xor(u2x4, d, 16);
+                }
+                if (l == 0) {
+                    const float fa = fac[v], fr = fac[32 + v];
+                    const float fax = ex_bits ? fadd_ex[slot] : 0.0f, frx = ex_bits ? fres_ex[slot] : 0.0f;
+                    const double S = (double)fax + (double)frx * dcu, B = fabs((double)frx) * sqrt((double)u2x4 * 0.25);
+                    const double S1 = (double)fa + (double)fr * dcb, B1 = fabs((double)fr) * sqrt((double)D) * 0.5;
+                    // rounded up (the f64 values themselves carry ~1e-13 relative error: one more ulp of f32 covers it)
+                    auto up32 = [](double x) { float f = (float)x; if ((double)f < x) f = nextafterf(f, INFINITY); return nextafterf(f, INFINITY); };
+                    sS[v] = up32(S); sB[v] = up32(B); sS1[v] = up32(S1); sB1[v] = up32(B1);
+                    sFa[v] = fabsf(fax); sFr[v] = fabsf(frx);
+                    sBad[v] = (finite_f(fa) && finite_f(fr) && finite_f(fax) && finite_f(frx) && isfinite(S) && isfinite(B) && isfinite(S1)) ? 0u : 1u;
+                }
+            } else if (l == 0) {
+                sS[v] = -INFINITY; sB[v] = 0.0f; sS1[v] = -INFINITY; sB1[v] = 0.0f; sFa[v] = 0.0f; sFr[v] = 0.0f; sBad[v] = 0u;
+            }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float S = sS[tid], B = sB[tid], S1 = sS1[tid], B1 = sB1[tid], Fa = sFa[tid], Fr = sFr[tid];
+            uint32_t bad = sBad[tid];
+#pragma unroll
+            for (int d = 16; d > 0; d >>= 1) {
+                S = fmaxf(S, __shfl_xor(S, d, 32)); B = fmaxf(B, __shfl_xor(B, d, 32));
+                S1 = fmaxf(S1, __shfl_xor(S1, d, 32)); B1 = fmaxf(B1, __shfl_xor(B1, d, 32));
+                Fa = fmaxf(Fa, __shfl_xor(Fa, d, 32)); Fr = fmaxf(Fr, __shfl_xor(Fr, d, 32));
+                bad |= __shfl_xor(bad, d, 32);
+            }
+            if (tid == 0) {
+                BlockSummaryEx bx;
+                bx.S = S; bx.B = B; bx.S1 = S1; bx.B1 = B1; bx.fadd_ex_abs = Fa; bx.fres_ex_abs = Fr; bx.usable = bad ? 0u : 1u; bx.pad = 0;
+                bsumx[gb0 + b] = bx;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < 64) {
+        const uint32_t lane = tid;
+        float amin = INFINITY, amax = -INFINITY, rmin = INFINITY, rmax = -INFINITY, emin = INFINITY, emax = -INFINITY;
+        uint32_t bad = nb == 0 ? 1u : 0u;
+        for (uint32_t b = lane; b < nb; b += 64) {
+            const BlockSummary bs = bsum[gb0 + b];
+            bad |= bs.usable ? 0u : 1u;
+            amin = fminf(amin, bs.fadd_min); amax = fmaxf(amax, bs.fadd_max);
+            rmin = fminf(rmin, bs.fres_min); rmax = fmaxf(rmax, bs.fres_max);
+            emin = fminf(emin, bs.ferr_min); emax = fmaxf(emax, bs.ferr_max);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            amin = fminf(amin, __shfl_xor(amin, d, 64)); amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+            rmin = fminf(rmin, __shfl_xor(rmin, d, 64)); rmax = fmaxf(rmax, __shfl_xor(rmax, d, 64));
+            emin = fminf(emin, __shfl_xor(emin, d, 64)); emax = fmaxf(emax, __shfl_xor(emax, d, 64));
+            bad |= __shfl_xor(bad, d, 64);
+        }
+        if (lane == 0) {
+            BlockSummary ls;
+            ls.usable = bad ? 0u : 1u; ls.pad = 0;
+            if (bad) { amin = amax = rmin = rmax = emin = emax = 0.0f; }
+            ls.fadd_min = amin; ls.fadd_max = amax; ls.fres_min = rmin; ls.fres_max = rmax; ls.ferr_min = emin; ls.ferr_max = emax;
+            lsum[c] = ls;
+        }
+    }
+}
+
 // histogram of the assignment; sets *err when an assignment is out of range
 __global__ void k_count_assign(const uint32_t* __restrict__ assign, uint64_t n, uint32_t nlist, uint32_t* __restrict__ counts,
                                uint32_t* __restrict__ err) {

@@ -37,6 +37,14 @@ hipError_t launch_block_summary(const uint8_t* blocks, const uint32_t* block_nv,
     hipLaunchKernelGGL(k_block_summary, dim3((nblocks + 7) / 8), dim3(256), 0, s, blocks, block_nv, nblocks, Dc, bsum);
     return hipGetLastError();
 }
+hipError_t launch_list_summaries(const uint8_t* blocks, const uint8_t* ex, const float* fadd_ex, const float* fres_ex, const float* cent,
+                                 const BlockSummary* bsum, const uint32_t* list_gb0, const uint32_t* list_n, uint32_t nlist, uint32_t D,
+                                 uint32_t Dc, uint32_t ex_bits, BlockSummaryEx* bsumx, BlockSummary* lsum, hipStream_t s) {
+    if (!nlist) return hipSuccess;
+    hipLaunchKernelGGL(k_list_summaries, dim3(nlist), dim3(256), (size_t)D * 4, s, blocks, ex, fadd_ex, fres_ex, cent, bsum, list_gb0,
+                       list_n, D, Dc, ex_bits, bsumx, lsum);
+    return hipGetLastError();
+}
 hipError_t launch_count_assign(const uint32_t* assign, uint64_t n, uint32_t nlist, uint32_t* counts, uint32_t* err, hipStream_t s) {
     hipLaunchKernelGGL(k_count_assign, dim3(1024), dim3(256), 0, s, assign, n, nlist, counts, err);
     return hipGetLastError();

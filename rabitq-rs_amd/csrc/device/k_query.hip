@@ -70,9 +70,12 @@ hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s) {
     return p.big ? launch_rank_f32<1, 2>(p, grid, s) : launch_rank_f32<1, 1>(p, grid, s);
 }
 
-hipError_t launch_select_exact(const SelectParams& p, hipStream_t s) {
+hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s) {
     const uint32_t np2 = next_pow2(p.nprobe);
     const size_t lds = (size_t)np2 * 8 + (size_t)p.D * 4 + kThreads * 4;
+    static LdsAttrCache attr; // nprobe > 4096: more than the default 64 KB of dynamic LDS
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_select), lds, device);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_select, dim3(p.nq), dim3(kThreads), lds, s, (const float*)p.scores, p.nlist, p.nprobe, np2, p.metric, p.rot,
                        p.cent, p.D, p.list_gb0, p.list_n, p.probe, p.wl, p.wl_stride, p.nstream, p.nvec, p.prof_total, p.consts,
                        p.bsum);
@@ -81,28 +84,34 @@ hipError_t launch_select_exact(const SelectParams& p, hipStream_t s) {
 
 namespace {
 template <int RM>
-hipError_t launch_select_rm(const SelectParams& p, uint32_t cap2, int row_in_lds, size_t lds, int stage, int device, hipStream_t s) {
+hipError_t launch_select_rm(const SelectParams& p, const SelectGeom& g, size_t lds, int device, hipStream_t s) {
     static LdsAttrCache attr;
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_select_mfma<RM>), lds, device);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_select_mfma<RM>, dim3(p.nq), dim3(kThreads), lds, s, p.scores, p.nlist, p.nprobe, cap2, row_in_lds, p.metric,
-                       p.rot, p.cent, p.D, p.consts, p.cnorm2_max, p.list_gb0, p.list_n, p.probe, p.wl, p.wl_stride, p.nstream,
-                       p.nvec, p.prof_total, p.fallback_count, p.force_fallback, p.bsum, stage);
+    hipLaunchKernelGGL(k_select_mfma<RM>, dim3(p.nq), dim3(kThreads), lds, s, p, g);
     return hipGetLastError();
 }
 } // namespace
 
 hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) {
-    const uint32_t cap2 = next_pow2(2 * p.nprobe) < 64u ? 64u : next_pow2(2 * p.nprobe);
-    const size_t lds0 = (size_t)cap2 * 8 + (size_t)p.D * 4 + kThreads * 4;
+    SelectGeom g;
+    g.cap2 = next_pow2(2 * p.nprobe) < 64u ? 64u : next_pow2(2 * p.nprobe);
+    const size_t lds0 = (size_t)g.cap2 * 8 + (size_t)p.D * 4 + kThreads * 4;
     // <= 4096 lists: the score row lives in registers; else in LDS while it fits beside the shortlist window
-    const int row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536 && lds0 + (size_t)p.nlist * 4 <= kLdsPerWorkgroupMax) ? 1 : 0;
-    size_t lds = lds0 + (row_in_lds ? (size_t)p.nlist * 4 : 0);
-    const int stage = lds + (size_t)p.nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
-    if (stage) lds += (size_t)p.nprobe * 16;
-    if (p.nlist <= 4096) return launch_select_rm<2>(p, cap2, row_in_lds, lds, stage, device, s);
-    if (row_in_lds) return launch_select_rm<1>(p, cap2, row_in_lds, lds, stage, device, s);
-    return launch_select_rm<0>(p, cap2, row_in_lds, lds, stage, device, s);
+    g.row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536 && lds0 + (size_t)p.nlist * 4 <= kLdsPerWorkgroupMax) ? 1 : 0;
+    size_t lds = lds0 + (g.row_in_lds ? (size_t)p.nlist * 4 : 0);
+    g.stage = lds + (size_t)p.nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
+    if (g.stage) lds += (size_t)p.nprobe * 16;
+    // LDS scorer of the lazy selection: RBQ_SEL_ROWS centroid rows at a time while the workgroup stays below 64 KB (>= 2 per CU)
+#ifndef RBQ_SEL_ROWS
+#define RBQ_SEL_ROWS 4
+#endif
+    const size_t rowsN = RBQ_SEL_ROWS * ((size_t)p.D + 8) * 4 + 16;
+    g.stage_rows = (p.lazy && lds + rowsN <= 64 * 1024) ? (uint32_t)RBQ_SEL_ROWS : 0u;
+    if (g.stage_rows) lds += rowsN;
+    if (p.nlist <= 4096) return launch_select_rm<2>(p, g, lds, device, s);
+    if (g.row_in_lds) return launch_select_rm<1>(p, g, lds, device, s);
+    return launch_select_rm<0>(p, g, lds, device, s);
 }
 
 hipError_t launch_probes_given(const ProbesGivenParams& p, hipStream_t s) {

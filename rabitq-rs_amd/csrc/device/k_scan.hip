@@ -2,6 +2,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <mutex>
+
 #include "launch.hpp"
 #include "scan.hpp"
 
@@ -10,9 +12,12 @@ namespace rbq {
 hipError_t LdsAttrCache::ensure(const void* fn, size_t lds, int device) {
     if (lds <= 48 * 1024) return hipSuccess; // default dynamic-LDS limit
     const int d = device & 15;
-    if (lds <= set[d]) return hipSuccess;
+    if (lds <= set[d].load(std::memory_order_acquire)) return hipSuccess;
+    static std::mutex mu; // one lock for all kernels: taken a handful of times per process
+    std::lock_guard<std::mutex> g(mu);
+    if (lds <= set[d].load(std::memory_order_relaxed)) return hipSuccess; // raised meanwhile by another caller
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) set[d] = lds; // (a racing caller at worst repeats the call)
+    if (e == hipSuccess) set[d].store(lds, std::memory_order_release);
     return e;
 }
 

@@ -39,6 +39,66 @@ __device__ __forceinline__ float block_lbmin(const BlockSummary& bs, float g_add
     return (bs.usable && fin) ? lbmin : -INFINITY;
 }
 
+// ---- bounds used by the lazy probe selection (k_select_mfma) ------------------------------------------------------------
+// Upper bound U of max(refined distance, lower bound) over the real vectors of one block of a list whose exact g_add /
+// g_err are known, from the block's Cauchy-Schwarz terms (BlockSummaryEx, derivation at k_list_summaries):
+//   refined distance <= S + g_add + B |q - c|,   lower bound <= 1-bit estimate <= S1 + g_add + B1 |q - c|
+// in exact arithmetic on the kernel's own inputs; |q - c| <= g_err (1 + 1e-4) (g_err = sqrt of the canonical f32 sum of
+// squares).  What the scan kernel COMPUTES differs from that by
+//   * the u8 quantisation of the LUT (src/ivf.rs:798-845): every codebook entry within delta/2 (+ rounding) of its f32
+//     value, D/4 codebooks:  |ip - <q, bit>| <= E_ip = (D/8) delta 1.01 + 1e-4 |q|_1   (the second term also covers the
+//     sequential f32 sums behind k1x / kbx and sum_vl),
+//   * the f32 summation of the ex-code dot (16-lane FMA chains + tree): <= 1e-3 (2^ex - 1) |q|_1  (actual: < 1.3e-4),
+//   * the roundings of the handful of f32 operations of the two formulas: 1e-5 of the sum of the magnitudes involved
+//     (each operation contributes at most 6e-8 of its operands), magnitudes bounded through the all-codes ranges.
+// +inf when anything is not finite (such a block proves nothing).
+__device__ __forceinline__ float block_ub(const BlockSummary& bs, const BlockSummaryEx& bx, float g_add, float g_err,
+                                          const QueryConsts& qc, uint32_t D, uint32_t ex_bits) {
+    const float ipA = fmaf(qc.delta, qc.amin, qc.sum_vl), ipB = fmaf(qc.delta, qc.amax, qc.sum_vl);
+    const float tmax = fmaxf(fabsf(ipA + qc.k1x), fabsf(ipB + qc.k1x));
+    const float ge = g_err * 1.0001f;
+    const float E_ip = (float)D * 0.125f * qc.delta * 1.01f + 1e-4f * qc.q1norm + 1e-6f * (fabsf(qc.sum_vl) + qc.delta * qc.amax);
+    const float fres_abs = fmaxf(fabsf(bs.fres_min), fabsf(bs.fres_max)), fadd_abs = fmaxf(fabsf(bs.fadd_min), fabsf(bs.fadd_max));
+    float est_hi = bx.S1 + g_add;
+    est_hi += bx.B1 * ge;
+    est_hi += fres_abs * E_ip;
+    est_hi += 1e-5f * (fadd_abs + fabsf(g_add) + fres_abs * tmax + fabsf(bx.S1) + bx.B1 * ge);
+    const float ferr_abs = fmaxf(fabsf(bs.ferr_min), fabsf(bs.ferr_max));
+    const float lb_hi = est_hi + fmaxf(-bs.ferr_min, 0.0f) * ge + 1e-5f * ferr_abs * ge; // lb = est - f_error * g_err
+    float d_hi = est_hi; // ex_bits == 0: distance = est
+    if (ex_bits) {
+        const float cmax = (float)((1u << ex_bits) - 1u);
+        const float uA = qc.scale * ipA + qc.exlo + qc.kbx, uB = qc.scale * ipB + qc.exhi + qc.kbx;
+        const float umax = fmaxf(fabsf(uA), fabsf(uB));
+        const float E_t = qc.scale * E_ip + 1e-3f * cmax * qc.q1norm;
+        d_hi = bx.S + g_add;
+        d_hi += bx.B * ge;
+        d_hi += bx.fres_ex_abs * E_t;
+        d_hi += 1e-5f * (bx.fadd_ex_abs + fabsf(g_add) + bx.fres_ex_abs * umax + fabsf(bx.S) + bx.B * ge);
+    }
+    const bool fin = bs.usable && bx.usable && isfinite(est_hi) && isfinite(lb_hi) && isfinite(d_hi) && isfinite(g_add) && isfinite(g_err);
+    return fin ? fmaxf(d_hi, lb_hi) : INFINITY;
+}
+// Whole-list bound: `ls` = the factor ranges over ALL blocks of a list, g_add in [ga_lo, ga_hi], g_err in [ge_lo, ge_hi]
+// (0 <= ge_lo).  True iff every vector of the list has a finite lower bound >= T for every admissible (g_add, g_err).
+__device__ __forceinline__ bool list_bound_reaches(const BlockSummary& ls, float ga_lo, float ga_hi, float ge_lo, float ge_hi,
+                                                   const QueryConsts& qc, float T) {
+    const float tA = fmaf(qc.delta, qc.amin, qc.sum_vl) + qc.k1x;
+    const float tB = fmaf(qc.delta, qc.amax, qc.sum_vl) + qc.k1x;
+    const float r0 = ls.fres_min * tA, r1 = ls.fres_min * tB, r2 = ls.fres_max * tA, r3 = ls.fres_max * tB;
+    const float rmin = fminf(fminf(r0, r1), fminf(r2, r3)), rmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    const float e0 = ls.ferr_min * ge_lo, e1 = ls.ferr_min * ge_hi, e2 = ls.ferr_max * ge_lo, e3 = ls.ferr_max * ge_hi;
+    const float emin = fminf(fminf(e0, e1), fminf(e2, e3)), emax = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+    float elo = ls.fadd_min + ga_lo;
+    elo = elo + rmin;
+    float ehi = ls.fadd_max + ga_hi;
+    ehi = ehi + rmax;
+    const float lbmin = elo - emax, lbmax = ehi - emin;
+    const bool fin = ls.usable && isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(r3) && isfinite(e0) && isfinite(e1) &&
+                     isfinite(e2) && isfinite(e3) && isfinite(elo) && isfinite(ehi) && isfinite(lbmin) && isfinite(lbmax);
+    return fin && lbmin >= T;
+}
+
 __device__ __forceinline__ int32_t total_key(float x) { // f32::total_cmp ordering key
     int32_t i = __float_as_int(x);
     return i ^ (int32_t)(((uint32_t)(i >> 31)) >> 1);

@@ -5,14 +5,18 @@
 //   k_scan.hip   k_scan<DT, EX, TR>                                               (scan.hpp)
 //   k_build.hip  encoder, reference-layout -> device-layout converters, sorting   (encode.hpp)
 #pragma once
+#include <atomic>
+
 #include "types.hpp"
 
 namespace rbq {
 
 // Raises a kernel's dynamic-LDS limit once per (kernel, device, size): hipFuncSetAttribute is slow and serialises
-// launches, so the largest value set so far is remembered per device.
+// launches, so the largest value set so far is remembered per device.  The limit is only ever RAISED, and the check-and-set
+// is serialised: two caller threads that need different sizes cannot leave the kernel with the smaller one.
 struct LdsAttrCache {
-    size_t set[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::atomic<size_t> set[16];
+    LdsAttrCache() { for (auto& v : set) v.store(0, std::memory_order_relaxed); }
     hipError_t ensure(const void* fn, size_t lds, int device);
 };
 
@@ -67,8 +71,17 @@ struct SelectParams {
     unsigned int* fallback_count;
     int force_fallback;
     const BlockSummary* bsum;
+    // lazy selection (k_select_mfma only): lists that are provably skipped as a whole are neither scored nor streamed
+    const float* cnorm2;          // [nlist] squared centroid norms (inner-product metric: distance from the approximate dot)
+    const BlockSummary* lsum;     // [nlist] factor ranges of every list
+    const BlockSummaryEx* bsumx;  // [n_blocks] ex-factor ranges of every block
+    uint32_t* dead_skipped;       // [4][nq] out: vectors of probed lists dropped that way (exact when exact_members, else 0) |
+                                  //              number of lists that go to the scan | two diagnostics taps (T_ub bits; z0, n, scored)
+    uint32_t top_k, ex_bits;
+    int lazy;                     // 0: every probed list is scored and streamed (round-2 behaviour)
+    int exact_members;            // diagnostics: dead_skipped and the probed-vector count must be exact
 };
-hipError_t launch_select_exact(const SelectParams& p, hipStream_t s);
+hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s);
 hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s);
 
 struct ProbesGivenParams {
@@ -100,6 +113,10 @@ hipError_t launch_pack_ex(const uint8_t* raw, const uint32_t* slot_src, const ui
                           uint32_t ex_bits, uint8_t* ex, hipStream_t s);
 hipError_t launch_block_summary(const uint8_t* blocks, const uint32_t* block_nv, uint32_t nblocks, uint32_t Dc, BlockSummary* bsum,
                                 hipStream_t s);
+// per-block Cauchy-Schwarz bound terms (BlockSummaryEx) and per-list factor ranges (lazy probe selection); one workgroup per list
+hipError_t launch_list_summaries(const uint8_t* blocks, const uint8_t* ex, const float* fadd_ex, const float* fres_ex, const float* cent,
+                                 const BlockSummary* bsum, const uint32_t* list_gb0, const uint32_t* list_n, uint32_t nlist, uint32_t D,
+                                 uint32_t Dc, uint32_t ex_bits, BlockSummaryEx* bsumx, BlockSummary* lsum, hipStream_t s);
 hipError_t launch_count_assign(const uint32_t* assign, uint64_t n, uint32_t nlist, uint32_t* counts, uint32_t* err, hipStream_t s);
 hipError_t launch_iota(uint32_t* x, uint64_t n, hipStream_t s);
 hipError_t launch_scatter_slots(const uint32_t* sorted_list, const uint32_t* sorted_src, uint64_t n, const uint32_t* list_gb0,

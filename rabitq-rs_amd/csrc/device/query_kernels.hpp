@@ -6,6 +6,16 @@
 
 namespace rbq {
 
+// Range of sum_i code_i * q_i over ALL ex codes (code_i in [0, 2^ex - 1]) from the sums of the positive and of the negative
+// query elements, widened by 1e-3 of the largest possible magnitude: that covers the rounding of these two sums and of the
+// scan kernel's own 16-lane FMA summation (each below D * 2^-24 <= 1.3e-4 relative for D <= 2048).
+__device__ __forceinline__ void ex_dot_range(float sum_pos, float sum_neg, uint32_t ex_bits, float& lo, float& hi) {
+    const float cmax = (float)((1u << ex_bits) - 1u);
+    const float slack = cmax * (sum_pos - sum_neg) * 1e-3f;
+    lo = cmax * sum_neg - slack;
+    hi = cmax * sum_pos + slack;
+}
+
 __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ queries, uint32_t dim, uint32_t D,
                                                    uint32_t Dc, int rotator, const uint8_t* __restrict__ rot_blob,
                                                    uint32_t trunc, float fac, uint32_t ex_bits,
@@ -17,7 +27,7 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
     float* y = sm + D;     // [D] (matrix rotator input)
     __shared__ int s_kmin, s_kmax;
     __shared__ unsigned int s_amin, s_amax;
-    __shared__ float s_sum, s_n2;
+    __shared__ float s_sum, s_n2, s_pos, s_neg;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const float* qin = queries + (size_t)q * dim;
 #ifdef RBQ_PREP_STAMPS
@@ -56,6 +66,11 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
             n2 = n2 + p;
         }
         s_n2 = n2;
+    }
+    if (tid == 128) { // sums of the positive / negative elements: range of the ex-code dot product (ex_dot_range)
+        float sp = 0.0f, sn = 0.0f;
+        for (uint32_t i = 0; i < D; ++i) { sp += fmaxf(x[i], 0.0f); sn += fminf(x[i], 0.0f); }
+        s_pos = sp; s_neg = sn;
     }
     __syncthreads();
 
@@ -140,9 +155,10 @@ __global__ __launch_bounds__(kThreads) void k_prep(const float* __restrict__ que
         qc.delta = delta;
         qc.sum_vl = vl * (float)(D / 4);
         qc.qnorm = sqrtf(s_n2);
-        qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
+        qc.qnorm2 = s_n2; qc.q1norm = (s_pos - s_neg) * 1.001f;
+        ex_dot_range(s_pos, s_neg, ex_bits, qc.exlo, qc.exhi);
 #ifdef RBQ_PREP_STAMPS
-        qc.pad0 = (float)(pt1 - pt0); qc.pad1 = (float)(pt2 - pt1); qc.pad2 = (float)(__builtin_amdgcn_s_memtime() - pt2);
+        qc.exlo = (float)(pt1 - pt0); qc.exhi = (float)(pt2 - pt1); qc.q1norm = (float)(__builtin_amdgcn_s_memtime() - pt2); // (lazy selection is off in this build)
 #endif
         qc.k1x = -0.5f * s_sum;
         const float cb = -((float)(1u << ex_bits) - 0.5f);
@@ -323,9 +339,12 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
         rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, rot_blob, trunc, fac, lane);
     }
 
+    float sp = 0.0f, sn = 0.0f; // sums of the positive / negative elements (ex_dot_range)
     for (uint32_t i = lane; i < D; i += 64) {
         const float v = x[i];
         x2[i] = v * v;
+        sp += fmaxf(v, 0.0f);
+        sn += fminf(v, 0.0f);
         rot_out[(size_t)q * D + i] = v;
         if (rot_hi) { // split-bf16 image for k_rank_bf16_db
             uint16_t h, l;
@@ -414,6 +433,8 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
     for (int d = 32; d > 0; d >>= 1) {
         amin += __shfl_xor(amin, d, 64);
         amax += __shfl_xor(amax, d, 64);
+        sp += __shfl_xor(sp, d, 64);
+        sn += __shfl_xor(sn, d, 64);
     }
     if (lane == 0) {
         QueryConsts qc;
@@ -422,9 +443,10 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
         qc.delta = delta;
         qc.sum_vl = vl * (float)(D / 4);
         qc.qnorm = sqrtf(s_n2);
-        qc.qnorm2 = s_n2; qc.pad0 = qc.pad1 = qc.pad2 = 0.0f;
+        qc.qnorm2 = s_n2; qc.q1norm = (sp - sn) * 1.001f;
+        ex_dot_range(sp, sn, ex_bits, qc.exlo, qc.exhi);
 #ifdef RBQ_PREP_STAMPS
-        qc.pad0 = (float)(pt1 - pt0); qc.pad1 = (float)(pt2 - pt1); qc.pad2 = (float)(__builtin_amdgcn_s_memtime() - pt2);
+        qc.exlo = (float)(pt1 - pt0); qc.exhi = (float)(pt2 - pt1); qc.q1norm = (float)(__builtin_amdgcn_s_memtime() - pt2); // (lazy selection is off in this build)
 #endif
         qc.k1x = -0.5f * s_sum;
         const float cb = -((float)(1u << ex_bits) - 0.5f);

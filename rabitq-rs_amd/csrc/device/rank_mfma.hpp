@@ -360,24 +360,224 @@ __device__ __forceinline__ void canon_pair2_ip_l2(const float* qrot, const float
 #else
 #define RBQ_SEL_BOUNDS __launch_bounds__(kThreads)
 #endif
+
+// launch geometry of k_select_mfma that the host derives from (nlist, nprobe, D): see launch_select_mfma
+struct SelectGeom {
+    uint32_t cap2;       // capacity of the shortlist window (power of two >= 2 * nprobe)
+    int row_in_lds;      // RM == 1: the approximate row is staged in LDS
+    int stage;           // per-probe geometry staged in LDS
+    uint32_t stage_rows; // centroid rows the LDS scorer stages at a time (0: no room, pair scorer only)
+};
+
+// ---- canonical scores of shortlist entries ----------------------------------------------------------------------------
+// Both scorers overwrite keys[e] (approximate key | cid) with the EXACT (score, cid) key of entry e = idx_of(j), j < m, and
+// park the canonical squared distance of an inner-product list in the (no longer needed) approximate row.  Same
+// accumulators, same order, bit-identical results.
+//   pairs : 2 lanes per list straight from global memory, 128 lists per round — every lane walks its row in dependent
+//           batches of 16-byte loads, each of which uses a quarter of the 32 cache lines it touches: the round-2 scorer, right
+//           when MANY lists are scored (it is bound by the L1 fill rate of those quarter-used lines)
+//   staged: `rows` lists at a time are loaded by the whole workgroup with fully coalesced 16-byte loads into LDS (one
+//           round trip, whole lines), then 8 lanes per list — one per accumulator of src/math.rs:216-245 — run the 120-step
+//           add chains from LDS: ~5 us for a handful of lists against ~45 us for a pair round.  What the lazy selection uses.
+template <typename IdxFn>
+__device__ __forceinline__ void canon_score_pairs(uint64_t* keys, const float* qrot, const float* __restrict__ cent, uint32_t D, int metric,
+                                                  float* grow, uint32_t m, uint32_t tid, IdxFn idx_of) {
+    const uint32_t l2 = tid & 1u, grp = tid >> 1;
+    for (uint32_t i0 = 0; i0 < m; i0 += kThreads / 2) {
+        const uint32_t j = i0 + grp;
+        uint32_t cid = 0, e = 0;
+        float s = 0.0f;
+        if (j < m) {
+            e = idx_of(j);
+            cid = (uint32_t)keys[e];
+            const float* c = cent + (size_t)cid * D;
+            if (metric == 0) s = canon_pair2<0>(qrot, c, D, l2);
+            else {
+                float dl2;
+                canon_pair2_ip_l2(qrot, c, D, l2, s, dl2);
+                if (l2 == 0) grow[cid] = dl2;
+            }
+        }
+        if (j < m && l2 == 0) keys[e] = make_key(s, cid, metric);
+    }
+}
+template <typename IdxFn>
+__device__ __forceinline__ void canon_score_staged(uint64_t* keys, const float* qrot, const float* __restrict__ cent, uint32_t D, int metric,
+                                                   float* grow, uint32_t m, uint32_t tid, float* rows, uint32_t RB, IdxFn idx_of) {
+    const uint32_t Dp = D + 8u, Dmain = D & ~7u, nv4 = D >> 2; // (+8 floats: the 8 lanes of consecutive rows hit distinct banks)
+    for (uint32_t base = 0; base < m; base += RB) {
+        const uint32_t nr = m - base < RB ? m - base : RB;
+        for (uint32_t x = tid; x < nr * nv4; x += kThreads) {
+            const uint32_t r = x / nv4, j4 = x - r * nv4;
+            const uint32_t cid = (uint32_t)keys[idx_of(base + r)];
+            *reinterpret_cast<float4*>(rows + (size_t)r * Dp + 4 * j4) = *reinterpret_cast<const float4*>(cent + (size_t)cid * D + 4 * j4);
+        }
+        __syncthreads();
+        if (tid < nr * 8u) {
+            const uint32_t r = tid >> 3, a = tid & 7u;
+            const float* c = rows + (size_t)r * Dp;
+            float acc = 0.0f, acc2 = 0.0f;
+            if (metric == 0) {
+#pragma unroll 8
+                for (uint32_t i = a; i < Dmain; i += 8) {
+                    const float d = qrot[i] - c[i];
+                    const float p = d * d;
+                    acc = acc + p;
+                }
+            } else {
+#pragma unroll 8
+                for (uint32_t i = a; i < Dmain; i += 8) {
+                    const float qv = qrot[i], cv = c[i];
+                    const float p = qv * cv;
+                    const float d = qv - cv;
+                    const float r2 = d * d;
+                    acc = acc + p;
+                    acc2 = acc2 + r2;
+                }
+            }
+            float sum = 0.0f, sum2 = 0.0f;
+            if (Dmain) {
+                sum = -0.0f; sum2 = -0.0f;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    sum = sum + __shfl(acc, l, 8);
+                    sum2 = sum2 + __shfl(acc2, l, 8);
+                }
+            }
+            for (uint32_t i = Dmain; i < D; ++i) { // scalar tail
+                const float qv = qrot[i], cv = c[i];
+                const float d = qv - cv;
+                const float r2 = d * d;
+                if (metric == 0) sum = sum + r2;
+                else {
+                    const float p = qv * cv;
+                    sum = sum + p;
+                    sum2 = sum2 + r2;
+                }
+            }
+            if (a == 0) {
+                const uint32_t e = idx_of(base + r);
+                const uint32_t cid = (uint32_t)keys[e];
+                keys[e] = make_key(sum, cid, metric);
+                if (metric == 1) { grow[cid] = sum2; __threadfence_block(); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// wave-wide minimum of one u32 per lane, on DPP (row_shr 1/2/4/8, row_bcast 15/31; the result is read from lane 63)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+    const int id = -1; // 0xffffffff: identity of the unsigned minimum
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x111, 0xf, 0xf, false); x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x112, 0xf, 0xf, false); x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x114, 0xf, 0xf, false); x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x118, 0xf, 0xf, false); x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x142, 0xa, 0xf, false); x = t < x ? t : x;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x143, 0xc, 0xf, false); x = t < x ? t : x;
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { // same DPP pattern, sum (missing lanes read 0)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// ascending sort of keys[0..n) (distinct keys; entries n..cap2-1 must be ~0 for the bitonic branch)
+__device__ __forceinline__ void sort_keys(uint64_t* keys, uint32_t n, uint32_t cap2, uint32_t tid) {
+    if (n <= 2 * kThreads) {
+        // rank sort: the keys are distinct (they carry the list id), so the number of smaller keys IS the
+        // position; every thread walks the n keys as LDS broadcasts — no barrier per compare-exchange stage
+        uint64_t my[2] = {~0ull, ~0ull};
+        uint32_t rk[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) my[u] = keys[tid + u * kThreads];
+        const uint32_t wbase = tid & ~63u;
+        // (unrolled: the loads of a group of keys are independent — one LDS round trip per 16 keys, not per key)
+        if (n > (uint32_t)kThreads) {
+#pragma unroll 8
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint64_t kj = keys[j];
+                rk[0] += kj < my[0] ? 1u : 0u;
+                rk[1] += kj < my[1] ? 1u : 0u;
+            }
+        } else if (wbase < n) {
+            const uint4* k2 = reinterpret_cast<const uint4*>(keys); // two keys per 16-byte read; slot n is ~0 (never smaller) when n is odd
+            const uint32_t np2 = (n + 1) >> 1;
+#pragma unroll 8
+            for (uint32_t j = 0; j < np2; ++j) {
+                const uint4 kk = k2[j];
+                const uint64_t ka = ((uint64_t)kk.y << 32) | kk.x, kb = ((uint64_t)kk.w << 32) | kk.z;
+                rk[0] += (ka < my[0] ? 1u : 0u) + (kb < my[0] ? 1u : 0u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) keys[rk[u]] = my[u];
+        __syncthreads();
+    } else {
+        for (uint32_t k = 2; k <= cap2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < cap2; i += kThreads) {
+                    const uint32_t ixj = i ^ j;
+                    if (ixj > i) {
+                        const uint64_t a = keys[i], b = keys[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+}
+
+constexpr uint32_t kSelHead = 4;       // nearest lists that are always scored and scanned: their blocks give the bound T_ub
+constexpr uint32_t kSelTodoMax = 256;  // lists the lazy path scores beyond the head (more: the query takes the eager path)
+constexpr uint32_t kSelZoneMax = 1024; // boundary-zone lists whose membership the lazy path resolves by counting
+
 // dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when RM == 1) |
-//              pgeo[4][nprobe] u32 (only when `stage`: g_add, g_err, first block, vector count of every probe)
+//              pgeo[4][nprobe] u32 (only when `stage`: g_add, g_err, first block, vector count of every probe) |
+//              rows[stage_rows][D + 8] f32 (LDS scorer)
 // RM: where the query's row of approximate scores lives during the selection passes — 2: in registers (nlist <=
 // 4096, 16 per thread), 1: staged in LDS, 0: re-read from global memory.
+//
+// LAZY SELECTION (round 3).  The reference scores every list exactly, sorts, probes the nprobe best in order
+// (src/ivf.rs:1782-1857) — and then skips, vector by vector, nearly all of them (97 % of the probed blocks on the bench
+// data).  A list whose EVERY vector the reference provably skips contributes nothing to the result but its size to
+// skipped_by_lower_bound: it needs neither its exact centroid distance (3840 B of centroid row at D = 960) nor stream
+// entries.  With A(c) the approximate score and eps the rigorous bound |A - canonical| <= eps of the header:
+//   cost(c) := g_add(c) (L2: the canonical distance; IP: -dot) lies in [+-A - eps, +-A + eps].
+//   1. shortlist S = {A within 2 eps of tau} as before, sorted by approximate cost.  Entry i is a CERTAIN member of the probe
+//      set iff fewer than nprobe lists can precede it: cost_i + 2 eps < cost of sorted entry nprobe (z0 = their number, a
+//      prefix).  The others form the boundary zone (no shortlisted list is a certain non-member, by construction of S).
+//   2. head = the first min(kSelHead, z0) entries: scored exactly.  For each of their blocks b, block_ub() bounds
+//      max(refined distance, lower bound) of its vectors by U(b) (Cauchy-Schwarz around the list's centroid: about
+//      (|r| + |q - c|)^2, i.e. within ~2x of the true distances).  T_ub := the smallest U with at least top_k vectors in
+//      head blocks of U(b) <= U.  Claim: once the reference has visited those blocks, its k-th distance is <= T_ub.  (Else
+//      each such vector v saw a threshold > T_ub >= lb_v, was evaluated, had a finite distance <= T_ub and was pushed:
+//      k pushed distances <= T_ub put the k-th smallest at or below T_ub.)  Thresholds only shrink afterwards.
+//   3. a list L outside the head is DEAD iff it certainly comes after every head list (cost_L - eps > max exact head cost)
+//      and list_bound_reaches(): every lb of L, for every admissible g_add / g_err, is finite and >= T_ub.  The reference
+//      then skips all of L's vectors wherever exactly L sits in its order.  Dead lists are neither scored nor streamed.
+//   4. everything not dead is scored exactly.  If a zone list is alive (or diagnostics / the profile want exact
+//      membership) ALL zone lists are scored, and a zone list is a member iff fewer than nprobe - z0 zone lists have a
+//      smaller exact key.  Scanned lists = members that are not dead, in exact (score, cid) order: the reference's order
+//      with the dead lists left out — its thresholds, pushes and results are untouched.
+//   diag: dead_skipped[q] = sum of n_c over dead members (added to skipped_by_lower_bound by k_scan).
+// Off (eager = every shortlisted list scored, every member streamed, the round-2 behaviour) when P.lazy == 0, with a
+// filter (filtered vectors are not pushed: no T_ub), when accu may wrap, and per query when T_ub is infinite or the
+// exceptional sizes above are exceeded.
 template <int RM>
-__global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint32_t nprobe,
-                                                          uint32_t cap2, int row_in_lds, int metric, const float* __restrict__ rot,
-                                                          const float* __restrict__ cent, uint32_t D,
-                                                          const QueryConsts* __restrict__ consts, float cnorm2_max,
-                                                          const uint32_t* __restrict__ list_gb0,
-                                                          const uint32_t* __restrict__ list_n,
-                                                          ProbeInfo* __restrict__ probe, StreamItem* __restrict__ wl,
-                                                          uint64_t wl_stride, uint32_t* __restrict__ nstream,
-                                                          unsigned long long* __restrict__ nvec_probed,
-                                                          unsigned long long* __restrict__ prof_total,
-                                                          unsigned int* __restrict__ fallback_count, int force_fallback,
-                                                          const BlockSummary* __restrict__ bsum, int stage) {
+__global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectGeom G) {
     extern __shared__ __align__(16) unsigned char smraw[];
+    const uint32_t nlist = P.nlist, nprobe = P.nprobe, cap2 = G.cap2, D = P.D;
+    const int metric = P.metric;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smraw);
     float* qrot = reinterpret_cast<float*>(smraw + (size_t)cap2 * 8);
     uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
@@ -390,11 +590,18 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
 #else
 #define SSTAMP()
 #endif
+#if defined(RBQ_SEL_STAMPS) && RBQ_SEL_STAMPS == 4
+    unsigned long long ls[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // sub-phases of the lazy branch
+#define LSTAMP(i) ls[i] = __builtin_amdgcn_s_memtime()
+#else
+#define LSTAMP(i)
+#endif
     SSTAMP();
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    float* grow = approx + (size_t)q * nlist;
+    float* grow = P.scores + (size_t)q * nlist;
     float* lrow = reinterpret_cast<float*>(part + kThreads); // RM == 1
     uint32_t* pgeo = reinterpret_cast<uint32_t*>(lrow + (RM == 1 ? nlist : 0u)); // `stage`
+    float* rows = reinterpret_cast<float*>(smraw + ((reinterpret_cast<unsigned char*>(pgeo + (G.stage ? 4u * nprobe : 0u)) - smraw + 15) & ~(size_t)15)); // LDS scorer
     constexpr int KPT = 16;
     uint32_t kreg[KPT]; // RM == 2: ordered keys of elements (u>>2)*1024 + 4*tid + (u&3)
     bool bad_load = false;
@@ -403,6 +610,13 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
         int32_t k = total_key(s);
         if (metric == 1) k = ~k;
         return (uint32_t)k ^ 0x80000000u;
+    };
+    // approximate COST (L2: the score; IP: -score; ascending = better) back from an ordered key
+    auto cost_of = [&](uint32_t k32) -> float {
+        int32_t k = (int32_t)(k32 ^ 0x80000000u);
+        if (metric == 1) k = ~k;
+        const float s = key_to_float(k);
+        return metric == 0 ? s : -s;
     };
     if (RM == 2) {
 #pragma unroll
@@ -432,7 +646,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
         }
     };
 
-    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = rot[(size_t)q * D + i];
+    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = P.rot[(size_t)q * D + i];
     if (tid == 0) { s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
     __syncthreads();
 
@@ -496,6 +710,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
                 if (tid < nc) {
                     const uint32_t my = cand[tid];
                     uint32_t less = 0, eq = 0;
+#pragma unroll 8
                     for (uint32_t j = 0; j < nc; ++j) {
                         const uint32_t kj = cand[j];
                         less += kj < my ? 1u : 0u;
@@ -512,8 +727,8 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
     }
     SSTAMP(); // 2: radix select done
     // 2. shortlist: approximate score within 2*eps of tau
-    const QueryConsts qc = consts[q];
-    const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + cnorm2_max) * 1.001f;
+    const QueryConsts qc = P.consts[q];
+    const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + P.cnorm2_max) * 1.001f;
     uint32_t cut = 0xffffffffu;
     if (!all) {
         // back from ordered key to the score value
@@ -524,87 +739,336 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
         cut = okey(lim);
         if (!finite_f(lim)) cut = 0xffffffffu;
     }
+    __shared__ uint32_t s_cntle, s_minab; // keys <= tau (more than nprobe: ties at tau) / smallest key above tau
     for (uint32_t i = tid; i < cap2; i += kThreads) keys[i] = ~0ull;
+    __shared__ uint32_t s_z0, s_tub, s_flag, s_need, s_dead, s_maxh, s_nh, s_nk, s_head[kSelHead]; // (s_tub, s_maxh: total_cmp keys of floats)
+    __shared__ unsigned long long s_memvec;
+    if (tid == 0) { s_cntle = 0; s_minab = 0xffffffffu;
+                    s_z0 = 0; s_tub = (uint32_t)total_key(INFINITY); s_flag = 0; s_need = 0; s_dead = 0; s_maxh = (uint32_t)total_key(-INFINITY); s_memvec = 0; s_nh = 0; s_nk = 0; }
+    if (tid < kSelHead) s_head[tid] = 0xffffffffu;
     __syncthreads();
-    bool fallback = s_bad != 0 || force_fallback != 0;
+    bool fallback = s_bad != 0 || P.force_fallback != 0;
     if (!fallback) {
+        uint32_t cle = 0, mab = 0xffffffffu;
         each_key([&](uint32_t i, uint32_t key) {
             if (key <= cut) {
                 const uint32_t p = atomicAdd(&s_cnt, 1u);
-                if (p < cap2) keys[p] = i; // cid for now; exact key after the canonical pass
+                if (p < cap2) keys[p] = ((uint64_t)key << 32) | i; // approximate key | cid; the exact key after scoring
+                if (all || key <= tau_key) ++cle;
+                else mab = key < mab ? key : mab;
             }
         });
+        cle = wave_sum_u32(cle);
+        mab = wave_min_u32(mab);
+        if ((tid & 63u) == 0) { if (cle) atomicAdd(&s_cntle, cle); if (mab != 0xffffffffu) atomicMin(&s_minab, mab); }
         __syncthreads();
         fallback = s_cnt > cap2 || s_cnt < nprobe;
     }
     __syncthreads();
     SSTAMP(); // 3: shortlist collected
     const uint32_t l2 = tid & 1u, grp = tid >> 1; // 128 pairs in flight
+    uint32_t m_scan = nprobe;      // lists that go to the scan (a prefix of keys[] in exact order at the end)
+    uint32_t dbg_tub = 0x7fc00000u, dbg_z = 0; // diagnostics taps: bits of T_ub (NaN: lazy path not entered) | z0, shortlist, scored
+    uint32_t dead_vec = 0;         // (thread 0) vectors of dead members
     if (!fallback) {
-        // 3. exact canonical scores of the shortlist, exact (score, cid) keys, sort
         const uint32_t n = s_cnt;
-        for (uint32_t i0 = 0; i0 < n; i0 += kThreads / 2) {
-            const uint32_t i = i0 + grp;
-            uint32_t cid = 0;
-            float s = 0.0f;
-            if (i < n) {
-                cid = (uint32_t)keys[i];
-                const float* c = cent + (size_t)cid * D;
-                if (metric == 0) s = canon_pair2<0>(qrot, c, D, l2);
-                else {
-                    float dl2;
-                    canon_pair2_ip_l2(qrot, c, D, l2, s, dl2);
-                    if (l2 == 0) grow[cid] = dl2; // the approximate row is not needed any more: park the distances there
-                }
+        // 3. certain members.  No sort by approximate cost is needed: the (nprobe+1)-th smallest approximate key is tau itself
+        // when more than nprobe shortlist keys are <= tau (ties), else the smallest key above tau (both counted by the
+        // shortlist pass).
+        LSTAMP(0);
+        __shared__ uint32_t s_wmin[4][kSelHead];
+        const uint32_t nown = (n + kThreads - 1 - tid) / kThreads; // entries tid, tid + 256, ... of this thread (n > tid)
+        unsigned long long m_certain = 0ull, m_dead = 0ull, m_apx = 0ull;
+        // what the classification (and the head selection) need of this thread's FIRST entry is requested now: one
+        // round trip under the passes below instead of one in front of each of them (entries 256.. load on demand)
+        BlockSummary ls_own = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, 0u};
+        uint32_t gb_own = 0, n_own = 0;
+        float cn_own = 0.0f;
+        if (P.lazy && tid < n) {
+            const uint32_t cid = (uint32_t)keys[tid];
+            ls_own = P.lsum[cid]; gb_own = P.list_gb0[cid]; n_own = P.list_n[cid];
+            if (metric == 1) cn_own = P.cnorm2[cid];
+        }
+        const uint32_t bound_key = (!all && s_cntle > nprobe) ? tau_key : s_minab;
+        const float cost_bound = (all || bound_key == 0xffffffffu) ? INFINITY : cost_of(bound_key);
+        {
+            uint32_t cnt = 0;
+            for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                const uint32_t k32 = (uint32_t)(keys[tid + u * kThreads] >> 32);
+                if (all || k32 <= tau_key) m_apx |= 1ull << u; // the approximate probe set (exactly nprobe lists unless keys tie at tau)
+                const bool cert = cost_of(k32) + 2.0f * eps < cost_bound;
+                if (cert) { m_certain |= 1ull << u; ++cnt; }
             }
-            if (i < n && l2 == 0) keys[i] = make_key(s, cid, metric);
+            cnt = wave_sum_u32(cnt);
+            if ((tid & 63u) == 0 && cnt) atomicAdd(&s_z0, cnt);
+        }
+        // the kSelHead smallest distinct approximate keys: per wave on DPP, then the 4 x 4 merged by every thread
+        {
+            uint32_t prev = 0;
+            const uint32_t wave = tid >> 6;
+#pragma unroll
+            for (uint32_t r = 0; r < kSelHead; ++r) {
+                uint32_t best = 0xffffffffu;
+                for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                    const uint32_t k32 = (uint32_t)(keys[tid + u * kThreads] >> 32);
+                    if ((r == 0 || k32 > prev) && k32 < best) best = k32;
+                }
+                best = wave_min_u32(best);
+                if ((tid & 63u) == 0) s_wmin[wave][r] = best;
+                prev = best;
+            }
         }
         __syncthreads();
-        SSTAMP(); // 4: canonical scores
-        if (cap2 <= 2 * kThreads) {
-            // rank sort: the keys are distinct (they carry the list id), so the number of smaller keys IS the
-            // position; every thread walks the n keys as LDS broadcasts — no barrier per compare-exchange stage
-            uint64_t my[2] = {~0ull, ~0ull};
-            uint32_t rk[2] = {0, 0};
+        const uint32_t z0 = s_z0; // certain members = the z0 smallest approximate costs
+#ifdef RBQ_PREP_STAMPS
+        const bool lazy_ok = false;
+#else
+        const bool lazy_ok = P.lazy != 0 && z0 > 0 && n - z0 <= kSelZoneMax && qc.amax <= 65535.0f && P.top_k > 0;
+#endif
+        uint32_t h = 0;
+        if (lazy_ok) {
+            // 4th smallest distinct key level of the workgroup; the head = up to kSelHead CERTAIN entries at or below it
+            uint32_t prev = 0, lvl = 0xffffffffu;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) my[u] = keys[tid + u * kThreads];
-            // (wavefronts without a key skip the walk; the second key slot is only walked when n > 256)
-            const uint32_t wbase = tid & ~63u;
-            if (n > (uint32_t)kThreads) {
-                for (uint32_t j = 0; j < n; ++j) {
-                    const uint64_t kj = keys[j];
-                    rk[0] += kj < my[0] ? 1u : 0u;
-                    rk[1] += kj < my[1] ? 1u : 0u;
+            for (uint32_t r = 0; r < kSelHead; ++r) {
+                uint32_t best = 0xffffffffu;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (uint32_t j = 0; j < kSelHead; ++j) {
+                        const uint32_t v = s_wmin[w][j];
+                        if ((r == 0 || v > prev) && v < best) best = v;
+                    }
+                if (best != 0xffffffffu) lvl = best;
+                prev = best;
+            }
+            for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                const uint32_t i = tid + u * kThreads;
+                if (((m_certain >> u) & 1ull) && (uint32_t)(keys[i] >> 32) <= lvl) {
+                    const uint32_t p = atomicAdd(&s_nh, 1u);
+                    if (p < kSelHead) s_head[p] = i;
                 }
-            } else if (wbase < n) {
-                for (uint32_t j = 0; j < n; ++j) rk[0] += keys[j] < my[0] ? 1u : 0u;
             }
             __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 2; ++u) if (tid + u * kThreads < n) keys[rk[u]] = my[u];
+            h = s_nh < kSelHead ? s_nh : kSelHead;
+        }
+        const uint32_t hp0 = lazy_ok ? s_head[0] : 0xffffffffu, hp1 = lazy_ok ? s_head[1] : 0xffffffffu,
+                       hp2 = lazy_ok ? s_head[2] : 0xffffffffu, hp3 = lazy_ok ? s_head[3] : 0xffffffffu; // positions of the head entries
+        auto is_head = [&](uint32_t i) { return i == hp0 || i == hp1 || i == hp2 || i == hp3; };
+        bool lazy = false;
+        LSTAMP(1);
+        if (lazy_ok && h > 0) {
+            // head geometry; the head lists are the first entries of the to-score list.  T_ub is computed from their
+            // APPROXIMATE costs widened by eps (the upper ends of g_add and g_err: block_ub() grows with both), so that no
+            // scoring round sits in front of the classification — everything that needs an exact score is scored in one
+            // round afterwards.
+            __shared__ uint32_t s_hgb[kSelHead], s_hn[kSelHead];
+            __shared__ float s_hcn[kSelHead];
+            if (tid < kSelHead) { s_hgb[tid] = 0; s_hn[tid] = 0; s_hcn[tid] = 0.0f; }
+            if (tid == 0) s_need = h;
             __syncthreads();
-        } else
-        for (uint32_t k = 2; k <= cap2; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = tid; i < cap2; i += kThreads) {
-                    const uint32_t ixj = i ^ j;
-                    if (ixj > i) {
-                        const uint64_t a = keys[i], b = keys[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+#pragma unroll
+            for (uint32_t r = 0; r < kSelHead; ++r) { // the owner of head entry r publishes its geometry
+                const uint32_t pos = r == 0 ? hp0 : r == 1 ? hp1 : r == 2 ? hp2 : hp3;
+                if (r < h && (pos & (kThreads - 1)) == tid) {
+                    uint32_t gb = gb_own, nv = n_own;
+                    float cn = cn_own;
+                    if (pos >= (uint32_t)kThreads) { const uint32_t cid = (uint32_t)keys[pos]; gb = P.list_gb0[cid]; nv = P.list_n[cid]; if (metric == 1) cn = P.cnorm2[cid]; }
+                    s_hgb[r] = gb; s_hn[r] = nv; s_hcn[r] = cn;
+                }
+            }
+            __syncthreads();
+            LSTAMP(2);
+            // upper ends of g_add / g_err and geometry of head list r
+            auto head_info = [&](uint32_t r, float& g_add, float& g_err, uint32_t& gb, uint32_t& nvec) {
+                const uint64_t key = keys[s_head[r]];
+                const float ci = cost_of((uint32_t)(key >> 32));
+                g_add = ci + eps;
+                if (metric == 0) g_err = sqrtf(fmaxf(g_add, 0.0f));
+                else g_err = sqrtf(fmaxf(qc.qnorm2 + s_hcn[r] + 2.0f * ci + 4.0f * eps, 0.0f)); // (as in the classification below)
+                gb = s_hgb[r]; nvec = s_hn[r];
+            };
+            // T_ub from up to 256 head blocks: thread t owns candidate block t
+            const uint32_t nb0 = (s_hn[0] + 31u) >> 5, nb1 = (s_hn[1] + 31u) >> 5, nb2 = (s_hn[2] + 31u) >> 5, nb3 = (s_hn[3] + 31u) >> 5;
+            static_assert(kSelHead == 4, "four head lists");
+            const uint32_t tot = nb0 + nb1 + nb2 + nb3;
+            const uint32_t ncand = tot < (uint32_t)kThreads ? tot : (uint32_t)kThreads;
+            float myU = INFINITY;
+            uint32_t myN = 0;
+            if (tid < ncand) {
+                uint32_t r = 0, b = tid;
+                if (b >= nb0) { b -= nb0; r = 1; if (b >= nb1) { b -= nb1; r = 2; if (b >= nb2) { b -= nb2; r = 3; } } }
+                float g_add, g_err; uint32_t gb, nvec;
+                head_info(r, g_add, g_err, gb, nvec);
+                const BlockSummary bs = P.bsum[gb + b];
+                const BlockSummaryEx bx = P.bsumx[gb + b];
+                myU = block_ub(bs, bx, g_add, g_err, qc, D, P.ex_bits) + 1e-4f * eps; // (+: |g_add| in the rounding slack is taken at the upper end)
+                myN = (b + 1 == ((nvec + 31u) >> 5)) ? nvec - b * 32u : 32u;
+            }
+            float* candU = reinterpret_cast<float*>(part);
+            candU[tid] = myU; hist[tid] = myN;
+            if (tid < h) { // largest possible head cost
+                float g_add, g_err; uint32_t gb, nvec;
+                head_info(tid, g_add, g_err, gb, nvec);
+                atomicMax(reinterpret_cast<int*>(&s_maxh), total_key(g_add)); // (s_maxh starts at the key of -inf)
+            }
+            __syncthreads();
+            if (tid < ncand && myU < INFINITY) {
+                uint32_t cum = 0;
+#pragma unroll 8
+                for (uint32_t j = 0; j < ncand; ++j) cum += candU[j] <= myU ? hist[j] : 0u;
+                if (cum >= P.top_k) atomicMin(reinterpret_cast<int*>(&s_tub), total_key(myU));
+            }
+            __syncthreads();
+            const float T_ub = key_to_float((int32_t)s_tub);
+            const float cost_maxh = key_to_float((int32_t)s_maxh);
+            lazy = T_ub < INFINITY;
+            dbg_tub = __float_as_uint(T_ub);
+            if (tid < h) hist[tid] = s_head[tid]; // (the candidate counts in `hist` have been read behind the barrier above)
+            LSTAMP(3);
+            if (lazy) {
+                // 3. classification of the entries beyond the head; what is alive goes straight to the to-score list (`hist`)
+                for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                    const uint32_t i = tid + u * kThreads;
+                    if (is_head(i)) continue;
+                    const uint64_t key = keys[i];
+                    const uint32_t cid = (uint32_t)key;
+                    const float ci = cost_of((uint32_t)(key >> 32));
+                    const float clo = ci - eps, chi = ci + eps;
+                    float ge_lo, ge_hi;
+                    if (metric == 0) { ge_lo = sqrtf(fmaxf(clo, 0.0f)); ge_hi = sqrtf(fmaxf(chi, 0.0f)); }
+                    else { // canonical squared distance = |q|^2 + |c|^2 - 2 dot, within 4 eps of this evaluation (rank_mfma.hpp header)
+                        const float da = qc.qnorm2 + (u == 0 ? cn_own : P.cnorm2[cid]) + 2.0f * ci;
+                        ge_lo = sqrtf(fmaxf(da - 4.0f * eps, 0.0f)); ge_hi = sqrtf(fmaxf(da + 4.0f * eps, 0.0f));
+                    }
+                    const BlockSummary ls = u == 0 ? ls_own : P.lsum[cid];
+                    const bool dead = clo > cost_maxh && list_bound_reaches(ls, clo, chi, ge_lo, ge_hi, qc, T_ub);
+                    if (dead) m_dead |= 1ull << u;
+                    else {
+                        if (!((m_certain >> u) & 1ull)) s_flag = 1u; // a zone list is alive
+                        const uint32_t p = atomicAdd(&s_need, 1u);
+                        if (p < kSelTodoMax) hist[p] = i;
                     }
                 }
                 __syncthreads();
+                const bool zone_scored = s_flag != 0u || P.exact_members != 0;
+                if (zone_scored) { // (uniform; without diagnostics only when a boundary-zone list is alive) the dead zone lists too
+                    for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                        const uint32_t i = tid + u * kThreads;
+                        if (!is_head(i) && ((m_dead >> u) & 1ull) && !((m_certain >> u) & 1ull)) {
+                            const uint32_t p = atomicAdd(&s_need, 1u);
+                            if (p < kSelTodoMax) hist[p] = i;
+                        }
+                    }
+                    __syncthreads();
+                }
+                LSTAMP(4);
+                lazy = s_need <= kSelTodoMax;
+                dbg_z = (z0 & 0x3ffu) | ((n & 0x3ffu) << 10) | (((s_need - h) & 0xfffu) << 20);
+                if (lazy) {
+                    // 4. score what is needed: the head and everything alive, in one round
+                    const uint32_t m = s_need;
+                    if (m) { // uniform
+                        auto todo_idx = [&](uint32_t j) { return hist[j]; };
+                        if (G.stage_rows && m <= 4u * G.stage_rows) canon_score_staged(keys, qrot, P.cent, D, metric, grow, m, tid, rows, G.stage_rows, todo_idx);
+                        else { canon_score_pairs(keys, qrot, P.cent, D, metric, grow, m, tid, todo_idx); __threadfence_block(); __syncthreads(); }
+                    }
+                    LSTAMP(5);
+                    // membership: certain, or a scored zone list with fewer than nprobe - z0 smaller zone keys (the zone
+                    // entries are marked in a bitset: only this — rare — step needs to know them from other threads)
+                    __shared__ uint32_t s_zone[512];
+                    __shared__ unsigned long long s_kept[kSelTodoMax];
+                    if (zone_scored) {
+                        for (uint32_t w = tid; w < 512; w += kThreads) s_zone[w] = 0u;
+                        __syncthreads();
+                        for (uint32_t u = 0; u < nown && tid < n; ++u)
+                            if (!((m_certain >> u) & 1ull)) { const uint32_t i = tid + u * kThreads; atomicOr(&s_zone[i >> 5], 1u << (i & 31u)); }
+                        __syncthreads();
+                    }
+                    unsigned long long m_keep = 0ull;
+                    uint32_t dv = 0;
+                    unsigned long long mv = 0;
+                    for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                        const uint32_t i = tid + u * kThreads;
+                        const bool cert = (m_certain >> u) & 1ull, dead = (m_dead >> u) & 1ull;
+                        bool member = cert;
+                        if (!cert && zone_scored) {
+                            const uint64_t my = keys[i];
+                            uint32_t less = 0;
+                            for (uint32_t j = 0; j < n; ++j) less += ((s_zone[j >> 5] >> (j & 31u)) & 1u) && keys[j] < my ? 1u : 0u;
+                            member = less < nprobe - z0;
+                        }
+                        if (member && !dead) {
+                            m_keep |= 1ull << u;
+                            const uint32_t p = atomicAdd(&s_nk, 1u);
+                            if (p < kSelTodoMax) s_kept[p] = keys[i];
+                        }
+                        // vectors of the probe set: exact under diagnostics; for the profile's algorithmic bytes alone, the
+                        // approximate probe set (the boundary zone is resolved only when something in it is alive)
+                        if (P.exact_members ? member : (P.prof_total != nullptr && ((m_apx >> u) & 1ull))) {
+                            const uint32_t nvec = P.list_n[(uint32_t)keys[i]];
+                            mv += nvec;
+                            if (dead && P.exact_members) dv += nvec;
+                        }
+                    }
+                    if (dv) atomicAdd(&s_dead, dv);
+                    if (mv) atomicAdd(&s_memvec, mv);
+                    __syncthreads(); // the kept keys are complete (and every membership count has read the zone keys)
+                    if (s_nk <= kSelTodoMax) {
+                        // the usual case, a handful of lists: rank sort from the side buffer straight into keys[0 .. m_scan)
+                        m_scan = s_nk;
+                        if (tid < m_scan) {
+                            const unsigned long long my = s_kept[tid];
+                            uint32_t rk = 0;
+#pragma unroll 4
+                            for (uint32_t j = 0; j < m_scan; ++j) rk += s_kept[j] < my ? 1u : 0u;
+                            keys[rk] = my;
+                        }
+                        __syncthreads();
+                    } else {
+                        // in-place compaction of the kept exact keys, chunk by chunk (a chunk's writes land at or below its
+                        // own first entry), then the tail is cleared for the sort
+                        uint32_t base = 0;
+                        for (uint32_t c0 = 0, u = 0; c0 < n; c0 += kThreads, ++u) {
+                            const uint32_t i = c0 + tid;
+                            const bool keep = i < n && ((m_keep >> u) & 1ull);
+                            const uint64_t v = i < n ? keys[i] : ~0ull;
+                            uint32_t total;
+                            const uint32_t off = block_scan_excl256(keep ? 1u : 0u, s_w4, tid, total);
+                            if (keep) keys[base + off] = v;
+                            base += total;
+                        }
+                        __syncthreads();
+                        m_scan = base;
+                        for (uint32_t i = m_scan + tid; i < cap2; i += kThreads) keys[i] = ~0ull;
+                        __syncthreads();
+                        sort_keys(keys, m_scan, cap2, tid);
+                    }
+                    LSTAMP(6);
+                    if (tid == 0) dead_vec = s_dead;
+                }
             }
+        }
+        if (!lazy) {
+            // eager: exact canonical scores of the whole shortlist, exact (score, cid) keys, sort; members = the first nprobe
+            auto all_idx = [](uint32_t j) { return j; };
+            canon_score_pairs(keys, qrot, P.cent, D, metric, grow, n, tid, all_idx);
+            __syncthreads();
+            SSTAMP(); // 4: canonical scores
+            sort_keys(keys, n, cap2, tid);
+        }
+#ifdef RBQ_SEL_STAMPS
+        else SSTAMP();
+#endif
     } else {
         // fallback (rare: shortlist overflow or non-finite approximate scores): overwrite this query's row
         // with canonical scores of EVERY list, then the exact 64-bit (score, cid) radix select of k_select
-        if (tid == 0 && fallback_count) atomicAdd(fallback_count, 1u);
+        if (tid == 0 && P.fallback_count) atomicAdd(P.fallback_count, 1u);
         float* row = grow;
         for (uint32_t base = 0; base < nlist; base += kThreads / 2) {
             const uint32_t cid = base + grp;
             if (cid < nlist) {
-                const float* c = cent + (size_t)cid * D;
+                const float* c = P.cent + (size_t)cid * D;
                 const float s = metric == 0 ? canon_pair2<0>(qrot, c, D, l2) : canon_pair2<1>(qrot, c, D, l2);
                 if (l2 == 0) row[cid] = s;
             }
@@ -665,29 +1129,29 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
     }
 
     SSTAMP(); // 5: sorted
-    // 4. per-probe constants (src/ivf.rs:1850-1857), block counts, work list — as k_select.
-    // IP needs the canonical centroid distance of every probed list as well (g_error): computed by the same
-    // 2-lane groups, 128 lists per round, and parked in the (now free) tail of the key buffer.
+    // 4. per-probe constants (src/ivf.rs:1850-1857), block counts, work list — as k_select — for the m_scan lists that go
+    // to the scan.  IP needs the canonical centroid distance of every such list as well (g_error): parked in the score row
+    // by the scorers, fetched into the (free) tail of the key buffer.
+    const uint32_t np = m_scan;
     float* dist_ip = reinterpret_cast<float*>(keys + nprobe); // cap2 >= 2*nprobe: room for nprobe floats
     if (metric == 1 && !fallback) {
-        // the shortlist pass left the canonical squared distance of every shortlisted list in the score row
         __threadfence_block();
         __syncthreads();
         const volatile float* vrow = grow; // written by other threads of this workgroup: read past the vector L1
-        for (uint32_t r = tid; r < nprobe; r += kThreads) {
+        for (uint32_t r = tid; r < np; r += kThreads) {
             dist_ip[r] = vrow[(uint32_t)(keys[r] & 0xffffffffu)]; // keys[0..nprobe) and the tail do not overlap
         }
         __syncthreads();
     } else if (metric == 1) {
-        for (uint32_t i0 = 0; i0 < nprobe; i0 += kThreads / 2) {
+        for (uint32_t i0 = 0; i0 < np; i0 += kThreads / 2) {
             const uint32_t r = i0 + grp;
             float d = 0.0f;
-            if (r < nprobe) {
+            if (r < np) {
                 const uint32_t cid = (uint32_t)(keys[r] & 0xffffffffu);
-                d = canon_pair2<0>(qrot, cent + (size_t)cid * D, D, l2);
+                d = canon_pair2<0>(qrot, P.cent + (size_t)cid * D, D, l2);
             }
             __syncthreads(); // all reads of keys[r] of this round done before the tail is written
-            if (r < nprobe && l2 == 0) dist_ip[r] = d;
+            if (r < np && l2 == 0) dist_ip[r] = d;
         }
         __syncthreads();
     }
@@ -711,18 +1175,18 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
     };
     // first stream position of every probe: workgroup prefix sum over the lists' block counts
     uint32_t* pstart = reinterpret_cast<uint32_t*>(dist_ip + nprobe); // cap2 >= 2*nprobe: room for nprobe words more
-    const uint32_t per = (nprobe + kThreads - 1) / kThreads;
-    const uint32_t r0 = tid * per, r1 = (r0 + per < nprobe) ? r0 + per : nprobe;
+    const uint32_t per = (np + kThreads - 1) / kThreads;
+    const uint32_t r0 = tid * per < np ? tid * per : np, r1 = (r0 + per < np) ? r0 + per : np;
     uint32_t local = 0;
     unsigned long long local_vec = 0;
     for (uint32_t r = r0; r < r1; ++r) {
         const ProbeInfo pi = probe_consts(r);
-        probe[(size_t)q * nprobe + r] = pi;
-        const uint32_t n = list_n[pi.cid];
-        if (stage) {
+        P.probe[(size_t)q * nprobe + r] = pi;
+        const uint32_t n = P.list_n[pi.cid];
+        if (G.stage) {
             pgeo[r] = __float_as_uint(pi.g_add);
             pgeo[nprobe + r] = __float_as_uint(pi.g_err);
-            pgeo[2 * nprobe + r] = list_gb0[pi.cid];
+            pgeo[2 * nprobe + r] = P.list_gb0[pi.cid];
             pgeo[3 * nprobe + r] = n;
         }
         local += (n + 31u) >> 5;
@@ -733,18 +1197,23 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
     uint32_t acc0 = block_scan_excl256(local, s_w4, tid, run);
     for (uint32_t r = r0; r < r1; ++r) {
         pstart[r] = acc0;
-        acc0 += ((stage ? pgeo[3 * nprobe + r] : list_n[(uint32_t)(keys[r] & 0xffffffffu)]) + 31u) >> 5;
+        acc0 += ((G.stage ? pgeo[3 * nprobe + r] : P.list_n[(uint32_t)(keys[r] & 0xffffffffu)]) + 31u) >> 5;
     }
     if (tid == 0) {
-        nstream[q] = run;
-        nvec_probed[q] = s_nvec;
-        if (prof_total) atomicAdd(prof_total, s_nvec);
+        P.nstream[q] = run;
+        // vectors of the probed lists (the scan's algorithmic work): scanned + dead members (exact when exact_members)
+        const unsigned long long nv = np == nprobe ? s_nvec : s_memvec;
+        P.nvec[q] = nv;
+        if (P.prof_total) atomicAdd(P.prof_total, nv);
+        if (P.dead_skipped) { // [1]: lists that go to the scan; [2], [3]: diagnostics taps of the lazy selection
+            P.dead_skipped[q] = dead_vec; P.dead_skipped[P.nq + q] = np;
+            P.dead_skipped[2 * (size_t)P.nq + q] = dbg_tub; P.dead_skipped[3 * (size_t)P.nq + q] = dbg_z;
+        }
     }
     __syncthreads();
     // the block stream, four entries per thread and step (their block summaries are all requested before the
     // first bound is evaluated): probe = last r with pstart[r] <= i
-    const QueryConsts qcs = consts[q];
-    StreamItem* out = wl + (size_t)q * wl_stride;
+    StreamItem* out = P.wl + (size_t)q * P.wl_stride;
     for (uint32_t base = 0; base < run; base += 4 * kThreads) {
         uint32_t rr[4], gbb[4], nvv[4];
         BlockSummary bs[4];
@@ -753,17 +1222,17 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
             const uint32_t i = base + u * kThreads + tid;
             rr[u] = 0; gbb[u] = 0; nvv[u] = 0;
             if (i < run) {
-                uint32_t lo = 0, hi = nprobe; // pstart[lo] <= i < pstart[hi] (pstart[nprobe] = run)
+                uint32_t lo = 0, hi = np; // pstart[lo] <= i < pstart[hi] (pstart[np] = run)
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (pstart[mid] <= i) lo = mid; else hi = mid;
                 }
                 // lists without vectors share their start with the next one: the LAST r with pstart[r] <= i owns i
                 uint32_t n, gb;
-                if (stage) { gb = pgeo[2 * nprobe + lo]; n = pgeo[3 * nprobe + lo]; }
+                if (G.stage) { gb = pgeo[2 * nprobe + lo]; n = pgeo[3 * nprobe + lo]; }
                 else {
                     const uint32_t cid = (uint32_t)(keys[lo] & 0xffffffffu);
-                    n = list_n[cid]; gb = list_gb0[cid];
+                    n = P.list_n[cid]; gb = P.list_gb0[cid];
                 }
                 const uint32_t nb = (n + 31u) >> 5, b = i - pstart[lo];
                 rr[u] = lo;
@@ -772,18 +1241,18 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bs[u] = bsum[gbb[u]]; // (block 0 for the idle slots)
+        for (int u = 0; u < 4; ++u) bs[u] = P.bsum[gbb[u]]; // (block 0 for the idle slots)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = base + u * kThreads + tid;
             if (i < run) {
                 float g_add, g_err;
-                if (stage) { g_add = __uint_as_float(pgeo[rr[u]]); g_err = __uint_as_float(pgeo[nprobe + rr[u]]); }
+                if (G.stage) { g_add = __uint_as_float(pgeo[rr[u]]); g_err = __uint_as_float(pgeo[nprobe + rr[u]]); }
                 else { const ProbeInfo pi = probe_consts(rr[u]); g_add = pi.g_add; g_err = pi.g_err; }
                 StreamItem wi;
                 wi.gblock = gbb[u];
                 wi.rank_nvalid = (rr[u] << 6) | nvv[u];
-                wi.lbmin = block_lbmin(bs[u], g_add, g_err, qcs);
+                wi.lbmin = block_lbmin(bs[u], g_add, g_err, qc);
                 wi.pad = 0;
                 out[i] = wi;
             }
@@ -795,12 +1264,15 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(float* approx, uint32_t nlist, uint
         unsigned long long pk = 0;
 #if RBQ_SEL_STAMPS == 2
         pk = ((ts[0] & 0xffffffffull) << 32) | ((ts[6] - ts[0]) & 0xffffffffull); // absolute start | duration
-        nvec_probed[q] = pk;
+        P.nvec[q] = pk;
 #elif RBQ_SEL_STAMPS == 3
-        nvec_probed[q] = s_cnt; // shortlist size
+        P.nvec[q] = ((unsigned long long)m_scan << 32) | s_cnt; // lists scanned | shortlist size
+#elif RBQ_SEL_STAMPS == 4
+        for (int t = 0; t < 6; ++t) pk |= ((ls[t + 1] > ls[t] ? (ls[t + 1] - ls[t]) >> 7 : 0ull) & 0x3ffull) << (10 * t); // 128-cycle units
+        P.nvec[q] = pk;
 #else
         for (int t = 0; t < 6; ++t) pk |= (((ts[t + 1] - ts[t]) >> 8) & 0x3ffull) << (10 * t); // 256-cycle units, 10 bits each
-        nvec_probed[q] = pk | ((unsigned long long)s_cnt << 60);
+        P.nvec[q] = pk | ((unsigned long long)s_cnt << 60);
 #endif
     }
 #endif

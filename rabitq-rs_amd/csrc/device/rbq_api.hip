@@ -10,6 +10,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,7 +93,7 @@ struct PinBuf { // page-locked host staging
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 8 + 4096;
-        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocPortable)); // portable: mapped for every device, not only the current one
         cap = want;
         return RBQ_OK;
     }
@@ -99,11 +102,11 @@ struct PinBuf { // page-locked host staging
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     void release() {
-        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter})
+        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped})
             b->release();
         h_in.release(); h_out.release();
         if (done) (void)hipEventDestroy(done);
@@ -150,9 +153,10 @@ struct Replica {
     uint64_t n_vectors = 0, n_lists = 0, n_blocks = 0;
     uint32_t trunc = 0;
     float fac = 1.0f;
-    Arr rot_blob, centroids, blocks, ids, ex, fadd_ex, fres_ex, list_gb0, list_n, prof, bsum, cnorm2, fallbacks, cent_hi, cent_lo, raw;
-    Arr* arrays[16] = {&rot_blob, &centroids, &blocks, &ids, &ex, &fadd_ex, &fres_ex, &list_gb0, &list_n, &prof, &bsum, &cnorm2,
-                       &fallbacks, &cent_hi, &cent_lo, &raw};
+    Arr rot_blob, centroids, blocks, ids, ex, fadd_ex, fres_ex, list_gb0, list_n, prof, bsum, cnorm2, fallbacks, cent_hi, cent_lo, raw,
+        bsumx, lsum; // ex-factor ranges per block, factor ranges per list (lazy probe selection)
+    Arr* arrays[18] = {&rot_blob, &centroids, &blocks, &ids, &ex, &fadd_ex, &fres_ex, &list_gb0, &list_n, &prof, &bsum, &cnorm2,
+                       &fallbacks, &cent_hi, &cent_lo, &raw, &bsumx, &lsum};
     float cnorm2_max = 0.0f;
     uint64_t n_raw = 0;      // raw vectors attached for the optional rerank
     bool raw_borrowed = false;
@@ -160,6 +164,7 @@ struct Replica {
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
+    bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     // host
     std::vector<uint32_t> h_list_n;
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
@@ -180,9 +185,49 @@ struct Replica {
 
 } // namespace
 
+namespace {
+// One persistent host thread per replica beyond the first (rbq_search_batch on N replicas): the shard of replica r is
+// enqueued and awaited by worker r while the caller's own thread serves replica 0.  Started on the first multi-replica
+// call, joined when the index is destroyed — no thread is created per call (8 replicas: seven thread start-ups of 30-50 us
+// each per call were as long as a 1024-query shard itself).
+struct ReplicaWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> jobs;
+    bool stop = false;
+    void start() {
+        th = std::thread([this] {
+            for (;;) {
+                std::function<void()> job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                    if (jobs.empty()) return; // stop requested and nothing left
+                    job = std::move(jobs.front());
+                    jobs.pop_front();
+                }
+                job();
+            }
+        });
+    }
+    void post(std::function<void()> job) {
+        { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(job)); }
+        cv.notify_one();
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
+} // namespace
+
 struct rbq_index {
     std::vector<Replica*> reps; // reps[r] lives on device reps[r]->device; all hold the same index
     int debug_replica = 0;      // which replica the rbq_debug_copy_* calls read
+    std::mutex worker_mu;
+    std::vector<std::unique_ptr<ReplicaWorker>> workers; // workers[r - 1] serves replica r (created on first use)
 };
 
 namespace {
@@ -214,6 +259,7 @@ void free_replica(Replica* ix) {
 }
 void free_index(rbq_index* h) {
     if (!h) return;
+    for (auto& w : h->workers) w->shutdown();
     for (Replica* r : h->reps) free_replica(r);
     delete h;
 }
@@ -295,6 +341,12 @@ int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
     double mx = 0;
     for (float v : cn) if (std::isfinite(v)) mx = std::max(mx, (double)v);
     ix->cnorm2_max = (float)(mx * 1.000001); // rounded up
+    if ((rc = alloc_arr(ix->lsum, (size_t)nlist * sizeof(BlockSummary)))) return rc;
+    if ((rc = alloc_arr(ix->bsumx, ix->n_blocks * sizeof(BlockSummaryEx)))) return rc;
+    HIP_TRY(launch_list_summaries((const uint8_t*)ix->blocks.p, (const uint8_t*)ix->ex.p, (const float*)ix->fadd_ex.p,
+                                  (const float*)ix->fres_ex.p, (const float*)ix->centroids.p, (const BlockSummary*)ix->bsum.p,
+                                  (const uint32_t*)ix->list_gb0.p, (const uint32_t*)ix->list_n.p, nlist, D, ix->Dc, ix->ex_bits,
+                                  (BlockSummaryEx*)ix->bsumx.p, (BlockSummary*)ix->lsum.p, 0));
     if ((rc = alloc_arr(ix->fallbacks, 8))) return rc;   // [0] rank fallbacks, [1] heap restarts
     HIP_TRY(hipMemset(ix->fallbacks.p, 0, 8));
     if ((rc = alloc_arr(ix->prof, kProfSlots * 8))) return rc;
@@ -303,7 +355,41 @@ int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
     ix->exact_rank = e && e[0] == '1';
     const char* f = std::getenv("RBQ_FORCE_RANK_FALLBACK");
     ix->force_rank_fallback = f && f[0] == '1';
+    const char* lz = std::getenv("RBQ_LAZY_SELECT");
+    ix->lazy_select = !(lz && lz[0] == '0');
     return RBQ_OK;
+}
+
+// Device-to-device copy between two replicas' devices: peer copy over xGMI when the runtime can (peer access is enabled
+// when the devices report it; hipMemcpyPeer itself stages through the host otherwise); if that fails, an explicit bounce
+// through a page-locked host buffer, 64 MB at a time.
+hipError_t copy_cross_device(void* dst, int ddev, const void* src, int sdev, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (ddev == sdev) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice);
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, ddev, sdev) == hipSuccess && can) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(sdev, 0); // (current device = ddev)
+        if (pe != hipSuccess) (void)hipGetLastError();            // already enabled, or refused: the copy below decides
+    } else {
+        (void)hipGetLastError();
+    }
+    hipError_t e = hipMemcpyPeer(dst, ddev, src, sdev, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    const size_t CH = (size_t)64 << 20;
+    void* bounce = nullptr;
+    e = hipHostMalloc(&bounce, std::min(bytes, CH), hipHostMallocPortable);
+    if (e != hipSuccess) return e;
+    for (size_t off = 0; off < bytes && e == hipSuccess; off += CH) {
+        const size_t n = std::min(CH, bytes - off);
+        e = hipSetDevice(sdev);
+        if (e == hipSuccess) e = hipMemcpy(bounce, (const uint8_t*)src + off, n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipSetDevice(ddev);
+        if (e == hipSuccess) e = hipMemcpy((uint8_t*)dst + off, bounce, n, hipMemcpyHostToDevice);
+    }
+    (void)hipSetDevice(ddev);
+    (void)hipHostFree(bounce);
+    return e;
 }
 
 // A second replica of `src` on device `dev` (may be the same device: exercised by tests on one GPU).
@@ -315,16 +401,13 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
     ix->dim = src->dim; ix->D = src->D; ix->Dc = src->Dc; ix->metric = src->metric; ix->rotator = src->rotator; ix->ex_bits = src->ex_bits;
     ix->n_vectors = src->n_vectors; ix->n_lists = src->n_lists; ix->n_blocks = src->n_blocks; ix->trunc = src->trunc; ix->fac = src->fac;
     ix->cnorm2_max = src->cnorm2_max; ix->h_list_n = src->h_list_n; ix->nblk_desc_prefix = src->nblk_desc_prefix;
-    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback;
+    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select;
     for (size_t i = 0; i < sizeof(ix->arrays) / sizeof(ix->arrays[0]); ++i) {
         const Arr* s = src->arrays[i];
         Arr* d = ix->arrays[i];
         if (!s->p || s == &src->raw) continue;
         hipError_t e = hipMalloc(&d->p, s->bytes ? s->bytes : 16);
-        if (e == hipSuccess && s->bytes) {
-            if (dev == src->device) e = hipMemcpy(d->p, s->p, s->bytes, hipMemcpyDeviceToDevice);
-            else e = hipMemcpyPeer(d->p, dev, s->p, src->device, s->bytes); // xGMI peer copy (staged through the host if no peer access)
-        }
+        if (e == hipSuccess && s->bytes) e = copy_cross_device(d->p, dev, s->p, src->device, s->bytes);
         if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, std::string("replicating the index: ") + hipGetErrorString(e)); }
         d->bytes = s->bytes;
     }
@@ -696,10 +779,21 @@ bool is_device_pointer(const void* p) {
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeDevice;
 }
-bool is_pinned_host_pointer(const void* p) {
-    hipPointerAttribute_t a;
+// The WHOLE range [p, p + bytes) is page-locked host memory of one allocation / registration: the kernels write (and the
+// DMA engines read) every byte of it, so a registration that covers only the first pages must not pass.
+bool is_pinned_host_range(const void* p, size_t bytes) {
+    if (!p) return false;
+    hipPointerAttribute_t a, b;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    if (a.type != hipMemoryTypeHost) return false;
+    if (bytes <= 1) return true;
+    const uint8_t* last = (const uint8_t*)p + bytes - 1;
+    if (hipPointerGetAttributes(&b, last) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (b.type != hipMemoryTypeHost) return false;
+    // same mapping: the device-side addresses of the two ends are as far apart as the host-side ones
+    if (a.devicePointer && b.devicePointer && (const uint8_t*)b.devicePointer - (const uint8_t*)a.devicePointer != (ptrdiff_t)(bytes - 1)) return false;
+    if (a.hostPointer && b.hostPointer && (const uint8_t*)b.hostPointer - (const uint8_t*)a.hostPointer != (ptrdiff_t)(bytes - 1)) return false;
+    return true;
 }
 
 int stream_begin_impl(const rbq_header* hdr, const float* centroids, const uint32_t* list_sizes, float t_const, int dev,
@@ -870,7 +964,7 @@ struct ProfScope {
 // k_scan launch shared by the IVF search and the MSTG posting-list scan
 int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, uint32_t top_k, uint64_t wl_stride,
                const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
-               rbq_diag* d_diag, bool mstg, hipStream_t stream) {
+               rbq_diag* d_diag, bool mstg, const uint32_t* d_dead_skipped, hipStream_t stream) {
     ProfScope ps(ix, 3, stream, /*ext=*/true);
     ScanParams P;
     P.blocks = (const uint8_t*)ix->blocks.p; P.ids = (const uint64_t*)ix->ids.p; P.ex_codes = (const uint8_t*)ix->ex.p;
@@ -886,6 +980,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.heap_restarts = (unsigned int*)ix->fallbacks.p + 1;
     P.mstg = mstg ? 1u : 0u;
     P.prof = ix->profiling ? (unsigned long long*)ix->prof.p : nullptr;
+    P.dead_skipped = d_dead_skipped;
     HIP_TRY(launch_scan(P, (uint32_t)nq, ix->device, stream, ps.start(), ps.stop()));
     return RBQ_OK;
 }
@@ -913,6 +1008,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     if ((rc = w->wl.ensure(nq * wl_stride * sizeof(StreamItem)))) return rc;
     if ((rc = w->nstream.ensure(nq * 4))) return rc;
     if ((rc = w->nvec.ensure(nq * 8))) return rc;
+    if ((rc = w->dead_skipped.ensure(nq * 16))) return rc;
     const bool split_rank = !ix->exact_rank && !ix->f32_rank && D % 64 == 0; // k_rank_bf16_db (else k_rank_mfma)
     if (split_rank) {
         if ((rc = w->rot_hi.ensure(nq * D * 2))) return rc;
@@ -942,15 +1038,21 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     sp.probe = (ProbeInfo*)w->probe.p; sp.wl = (StreamItem*)w->wl.p; sp.wl_stride = wl_stride; sp.nstream = (uint32_t*)w->nstream.p;
     sp.nvec = (unsigned long long*)w->nvec.p; sp.prof_total = prof; sp.fallback_count = (unsigned int*)ix->fallbacks.p;
     sp.force_fallback = ix->force_rank_fallback ? 1 : 0; sp.bsum = (const BlockSummary*)ix->bsum.p;
+    sp.cnorm2 = (const float*)ix->cnorm2.p; sp.lsum = (const BlockSummary*)ix->lsum.p; sp.bsumx = (const BlockSummaryEx*)ix->bsumx.p;
+    sp.dead_skipped = (uint32_t*)w->dead_skipped.p; sp.top_k = top_k; sp.ex_bits = ix->ex_bits;
+    // lazy selection: not with a filter (filtered vectors are never pushed, so no select-time bound of the k-th distance
+    // exists) and not when every probed block is to be streamed
+    sp.lazy = (ix->lazy_select && !d_filter && !ix->no_block_bound) ? 1 : 0;
+    sp.exact_members = d_diag ? 1 : 0;
     if (ix->exact_rank) {
         { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_exact(rp, stream)); }
-        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, stream)); }
+        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, ix->device, stream)); }
     } else {
         { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); }           // approximate scores: one MFMA GEMM
         { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
     if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
-                         /*mstg=*/false, stream)))
+                         /*mstg=*/false, ix->exact_rank ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
         return rc;
     if (ix->rerank) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
         HIP_TRY(launch_rerank(d_queries, (uint32_t)nq, ix->dim, (const float*)ix->raw.p, ix->n_raw, ix->metric, top_k, d_ids, d_scores,
@@ -998,13 +1100,15 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     double t_attr = 0, t_ws = 0, t_stage = 0, t_enq = 0, t_wait = 0, t_out = 0;
     auto tick = [&](clk::time_point& t0, double& acc) { if (trace) { const auto t1 = clk::now(); acc += std::chrono::duration<double, std::micro>(t1 - t0).count(); t0 = t1; } };
     clk::time_point tp = clk::now();
-    uint64_t SB = ix->host_subbatch ? ix->host_subbatch : 1024; // (also bounds the nq x nlist score matrix per lane)
+    // sub-batch: 1024 queries (also bounds the nq x nlist score matrix per lane); a call (or replica shard) of fewer than
+    // 2048 queries is cut in two, so that the H2D copy and the kernels of its halves overlap on two lanes
+    uint64_t SB = ix->host_subbatch ? ix->host_subbatch : (nq >= 2048 ? 1024 : std::max<uint64_t>(256, (nq + 1) / 2));
     SB = std::min<uint64_t>(SB, nq);
     const uint64_t nsub = (nq + SB - 1) / SB;
     const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 6u);
-    const bool in_pinned = is_pinned_host_pointer(queries);
-    bool out_pinned = !ix->rerank && is_pinned_host_pointer(out_ids) && is_pinned_host_pointer(out_scores) &&
-                      is_pinned_host_pointer(out_counts) && (!diag || is_pinned_host_pointer(diag));
+    const bool in_pinned = is_pinned_host_range(queries, nq * query_dim * 4);
+    bool out_pinned = !ix->rerank && is_pinned_host_range(out_ids, nq * top_k * 8) && is_pinned_host_range(out_scores, nq * top_k * 4) &&
+                      is_pinned_host_range(out_counts, nq * 4) && (!diag || is_pinned_host_range(diag, nq * sizeof(rbq_diag)));
     // device-side addresses of page-locked caller buffers (identical under unified addressing; asked for, not assumed)
     uint64_t* c_ids = nullptr; float* c_scores = nullptr; uint32_t* c_counts = nullptr; rbq_diag* c_diag = nullptr;
     if (out_pinned) {
@@ -1389,10 +1493,20 @@ int rbq_search_batch(const rbq_index* ch, const float* queries, uint64_t nq, uin
     const size_t R = h->reps.size();
     if (R == 1 || nq < 2 * R) return search_host(h->reps[0], queries, nq, query_dim, top_k, nprobe, filter_words, filter_nbits, out_ids,
                                                   out_scores, out_counts, diag);
-    // N replicas: contiguous shards [r*nq/R, (r+1)*nq/R), one host thread per replica (batch_search is a par_iter over
-    // queries, src/ivf.rs:1743-1752); results land straight in the caller's arrays, no exchange between devices
+    // N replicas: contiguous shards [r*nq/R, (r+1)*nq/R) (batch_search is a par_iter over queries, src/ivf.rs:1743-1752);
+    // replica 0 is served by the calling thread, replica r > 0 by its persistent worker thread; results land straight in
+    // the caller's arrays, no exchange between devices
+    {
+        std::lock_guard<std::mutex> lk(h->worker_mu);
+        while (h->workers.size() + 1 < R) {
+            h->workers.emplace_back(new ReplicaWorker());
+            h->workers.back()->start();
+        }
+    }
     std::vector<int> rcs(R, RBQ_OK);
     std::vector<std::string> details(R);
+    struct Latch { std::mutex mu; std::condition_variable cv; size_t left; } latch;
+    latch.left = R - 1;
     auto shard = [&](size_t r) {
         const uint64_t q0 = r * nq / R, q1 = (r + 1) * nq / R;
         try {
@@ -1401,10 +1515,17 @@ int rbq_search_batch(const rbq_index* ch, const float* queries, uint64_t nq, uin
         } catch (...) { rcs[r] = RBQ_IO; g_err = "internal error"; }
         details[r] = g_err; // thread-local in the worker
     };
-    std::vector<std::thread> th;
-    for (size_t r = 1; r < R; ++r) th.emplace_back(shard, r);
+    for (size_t r = 1; r < R; ++r)
+        h->workers[r - 1]->post([&, r] {
+            shard(r);
+            std::lock_guard<std::mutex> lk(latch.mu);
+            if (--latch.left == 0) latch.cv.notify_one();
+        });
     shard(0);
-    for (auto& t : th) t.join();
+    {
+        std::unique_lock<std::mutex> lk(latch.mu);
+        latch.cv.wait(lk, [&] { return latch.left == 0; });
+    }
     for (size_t r = 0; r < R; ++r) if (rcs[r]) return fail(rcs[r], details[r]);
     return RBQ_OK;
     RBQ_GUARD_END
@@ -1493,7 +1614,7 @@ int rbq_posting_scan_batch(const rbq_index* ch, const float* queries, uint64_t n
                 HIP_TRY(launch_probes_given(p, st));
             }
             if ((r2 = scan_stage(ix, w, n, max_lists, top_k, wl_stride, nullptr, 0, (uint64_t*)(dp + op.o_ids), (float*)(dp + op.o_scores),
-                                 (uint32_t*)(dp + op.o_counts), nullptr, /*mstg=*/true, st)))
+                                 (uint32_t*)(dp + op.o_counts), nullptr, /*mstg=*/true, nullptr, st)))
                 return r2;
             HIP_TRY(hipMemcpyAsync(out_ids + q0 * top_k, dp + op.o_ids, n * top_k * 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(out_scores + q0 * top_k, dp + op.o_scores, n * top_k * 4, hipMemcpyDeviceToHost, st));
@@ -1514,23 +1635,49 @@ int rbq_index_set_rerank_vectors(rbq_index* h, const float* vectors, uint64_t n)
     g_err.clear();
     RBQ_GUARD_BEGIN
     if (!h || h->reps.empty()) return fail(RBQ_INVALID_CONFIG, "null index");
-    for (Replica* ix : h->reps) {
+    // all replicas or none: the new copies are made first; only when every one of them exists are the old ones released
+    // and the new ones attached (a failure half-way leaves every replica exactly as it was)
+    const size_t R = h->reps.size();
+    std::vector<Arr> fresh(R);
+    std::vector<char> borrowed(R, 0);
+    const bool attach = vectors && n;
+    if (attach) {
+        hipPointerAttribute_t a;
+        const bool on_dev = hipPointerGetAttributes(&a, vectors) == hipSuccess && a.type == hipMemoryTypeDevice;
+        if (!on_dev) (void)hipGetLastError();
+        int rc = RBQ_OK;
+        for (size_t r = 0; r < R && rc == RBQ_OK; ++r) {
+            Replica* ix = h->reps[r];
+            DeviceGuard g(ix->device);
+            if (!g.ok) { rc = fail(RBQ_DEVICE, "hipSetDevice failed"); break; }
+            const size_t bytes = (size_t)n * ix->dim * 4;
+            if (on_dev && a.device == ix->device) { // borrowed: stays owned by the caller, must outlive the index
+                fresh[r].p = const_cast<float*>(vectors); fresh[r].bytes = bytes; borrowed[r] = 1;
+                continue;
+            }
+            rc = alloc_arr(fresh[r], bytes);
+            if (rc == RBQ_OK) {
+                const hipError_t e = on_dev ? copy_cross_device(fresh[r].p, ix->device, vectors, a.device, bytes)
+                                            : hipMemcpy(fresh[r].p, vectors, bytes, hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(RBQ_DEVICE, std::string("attaching the rerank vectors: ") + hipGetErrorString(e));
+            }
+        }
+        if (rc != RBQ_OK) {
+            const std::string keep = g_err;
+            for (size_t r = 0; r < R; ++r)
+                if (fresh[r].p && !borrowed[r]) { DeviceGuard g(h->reps[r]->device); (void)hipFree(fresh[r].p); }
+            return fail(rc, keep);
+        }
+    }
+    for (size_t r = 0; r < R; ++r) {
+        Replica* ix = h->reps[r];
         DeviceGuard g(ix->device);
         if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
         HIP_TRY(hipDeviceSynchronize());
         if (ix->raw.p && !ix->raw_borrowed) (void)hipFree(ix->raw.p);
         ix->raw = Arr(); ix->n_raw = 0; ix->rerank = false; ix->raw_borrowed = false;
-        if (!vectors || n == 0) continue; // detach
-        hipPointerAttribute_t a;
-        const bool on_dev = hipPointerGetAttributes(&a, vectors) == hipSuccess && a.type == hipMemoryTypeDevice;
-        if (!on_dev) (void)hipGetLastError();
-        if (on_dev && a.device == ix->device) { // borrowed: stays owned by the caller, must outlive the index
-            ix->raw.p = const_cast<float*>(vectors); ix->raw.bytes = (size_t)n * ix->dim * 4; ix->raw_borrowed = true;
-        } else {
-            int rc = alloc_arr(ix->raw, (size_t)n * ix->dim * 4);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpy(ix->raw.p, vectors, (size_t)n * ix->dim * 4, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-        }
+        if (!attach) continue; // detach
+        ix->raw = fresh[r]; ix->raw_borrowed = borrowed[r] != 0;
         ix->n_raw = n; ix->rerank = true;
     }
     return RBQ_OK;
@@ -1626,6 +1773,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         if (!std::strcmp(name, "block_bound")) ix->no_block_bound = value == 0;
         else if (!std::strcmp(name, "exact_rank")) ix->exact_rank = value != 0;
         else if (!std::strcmp(name, "exact_heap")) ix->exact_heap = value != 0;
+        else if (!std::strcmp(name, "lazy_select")) ix->lazy_select = value != 0;
         else if (!std::strcmp(name, "f32_rank")) ix->f32_rank = value != 0;
         else if (!std::strcmp(name, "wg_prep")) ix->wg_prep = value != 0;
         else if (!std::strcmp(name, "small_rank_tiles")) ix->small_rank_tiles = value != 0;
@@ -1677,6 +1825,7 @@ int rbq_debug_copy_workspace(rbq_index* h, void* hip_stream, const char* name, v
     else if (!std::strcmp(name, "nstream")) b = &w->nstream;
     else if (!std::strcmp(name, "wl")) b = &w->wl;
     else if (!std::strcmp(name, "nvec")) b = &w->nvec;
+    else if (!std::strcmp(name, "dead_skipped")) b = &w->dead_skipped;
     if (!b || !b->p || bytes > b->cap) return fail(RBQ_INVALID_CONFIG, "unknown buffer or size");
     DeviceGuard g(ix->device);
     HIP_TRY(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));
@@ -1699,6 +1848,8 @@ int rbq_debug_copy_index(rbq_index* h, const char* name, void* dst, uint64_t byt
     else if (!std::strcmp(name, "fadd_ex")) { p = ix->fadd_ex.p; have = ix->ex_bits ? slots * 4 : 0; }
     else if (!std::strcmp(name, "fres_ex")) { p = ix->fres_ex.p; have = ix->ex_bits ? slots * 4 : 0; }
     else if (!std::strcmp(name, "bsum")) { p = ix->bsum.p; have = ix->n_blocks * sizeof(BlockSummary); }
+    else if (!std::strcmp(name, "lsum")) { p = ix->lsum.p; have = ix->n_lists * sizeof(BlockSummary); }
+    else if (!std::strcmp(name, "bsumx")) { p = ix->bsumx.p; have = ix->n_blocks * sizeof(BlockSummaryEx); }
     else if (!std::strcmp(name, "centroids")) { p = ix->centroids.p; have = ix->n_lists * ix->D * 4; }
     else if (!std::strcmp(name, "list_gb0")) { p = ix->list_gb0.p; have = ix->n_lists * 4; }
     else if (!std::strcmp(name, "list_n")) { p = ix->list_n.p; have = ix->n_lists * 4; }

@@ -1371,7 +1371,8 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         P.out_counts[q] = len;
         if (P.diag) {
             P.diag[(size_t)q * 3 + 0] = n_est;
-            P.diag[(size_t)q * 3 + 1] = *s_nskip;
+            // + the vectors of probed lists that the probe selection proved skipped as a whole (never streamed)
+            P.diag[(size_t)q * 3 + 1] = *s_nskip + (P.dead_skipped ? P.dead_skipped[q] : 0u);
             P.diag[(size_t)q * 3 + 2] = ex_bits ? n_ext : 0;
         }
     }

@@ -12,7 +12,10 @@ constexpr int kThreads = 256;
 
 struct QueryConsts {
     float delta, sum_vl, k1x, kbx, scale, qnorm;
-    float qnorm2, pad0, pad1, pad2; // |q|^2 of the rotated query (approximate ranking, rank_mfma.hpp)
+    float qnorm2;     // |q|^2 of the rotated query (approximate ranking, rank_mfma.hpp)
+    float exlo, exhi; // the ex-code dot product sum_i code_i * q_i of ANY code (code_i in [0, 2^ex - 1]) lies in [exlo, exhi],
+                      // rounding of the kernel's own summation included (lazy probe selection, rank_mfma.hpp)
+    float q1norm;     // sum_i |q_i| of the rotated query (rounding slack of that selection)
     float amin, amax; // sum over codebooks of the smallest / largest u8 entry: accu of ANY code lies in [amin, amax]
 };
 struct ProbeInfo {
@@ -28,6 +31,15 @@ struct WorkItem {
 // bound: lbmin <= lb_v <= lbmax.  `usable` is 0 when any factor is non-finite (the block is then never skipped).
 struct BlockSummary {
     float fadd_min, fadd_max, fres_min, fres_max, ferr_min, ferr_max;
+    uint32_t usable, pad;
+};
+// Per-block maxima over the block's REAL vectors of the quantities that bound, by Cauchy-Schwarz around the list's
+// centroid, the refined distance and the 1-bit estimate of every vector for ANY query (k_list_summaries, encode.hpp):
+//   refined distance <= S + g_add + B * g_err,   1-bit estimate <= S1 + g_add + B1 * g_err   (+ rounding slack, block_ub()).
+// fadd_ex_abs / fres_ex_abs: largest |f_add_ex| / |f_rescale_ex| (magnitudes for that slack).  usable = 0: a factor of the
+// block is not finite (the block then proves nothing).
+struct BlockSummaryEx {
+    float S, B, S1, B1, fadd_ex_abs, fres_ex_abs;
     uint32_t usable, pad;
 };
 // One entry of a query's block stream (probe order, block order within a list).  `lbmin` is the block-level
@@ -86,6 +98,8 @@ struct ScanParams {
     uint32_t mstg;           // MSTG posting-list semantics (src/mstg/index.rs:216-330): distance = binary estimate,
                              // non-finite dropped, L2 clamped to >= 0, no error-bound term
     unsigned long long* prof; // null, or the traffic counters of kProf* below (one atomicAdd per workgroup at exit)
+    const uint32_t* dead_skipped; // [nq] vectors of probed lists that the probe selection proved skipped as a whole (they
+                                  // never enter the stream; diagnostics add them to skipped_by_lower_bound), or null
 };
 // traffic counters kept while a profile is open (rbq_profile_begin/end); [0] is written by the select kernels
 enum { kProfVectorsProbed = 0, kProfCodeBlocks = 1, kProfMetaBlocks = 2, kProfStreamEntries = 3, kProfExEvals = 4,

@@ -601,7 +601,7 @@ def test_bench_two_rank_rehearsal():
     env = dict(os.environ, RBQ_BENCH_REHEARSAL="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-extras", "--nbatches", "3"], env=env,
+                          "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-extras", "--nbatches", "3", "--min-seconds", "0", "--no-latency"], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -626,12 +626,13 @@ def test_bench_rccl_single_rank_group():
     env.pop("RBQ_BENCH_REHEARSAL", None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                          "--gpus", "1", "--steps", "12", "--warmup", "2", "--no-extras", "--no-cpu", "--nbatches", "4"], env=env,
+                          "--gpus", "1", "--steps", "12", "--warmup", "2", "--no-extras", "--no-cpu", "--nbatches", "4", "--min-seconds", "0", "--no-latency"], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["pruned"]["launches"] == 12 and d["recall_at_10"] > 0.9
-    assert d["roofline"]["ids_identical_to_product_configuration"]
+    assert d["roofline"]["ids_identical_to_product_configuration"] and d["rccl_world_size"] == 1 and len(d["per_rank_queries_per_s"]) == 1
+    assert d["self_check"]["ids_identical"] and d["self_check"]["score_bits_identical"]
 
 
 def test_library_first_then_torch_in_a_fresh_process():

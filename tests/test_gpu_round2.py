@@ -36,6 +36,7 @@ def test_stage_level_parity(n, dim, nlist, bits, metric, rot, nq, nprobe, unifor
     data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot, uniform=uniform,
                               normalize=(metric == 1), seed=3000 + dim + bits, faster=faster)
     idx = rq.IvfRabitqIndex.from_built(built)
+    idx.set_option("lazy_select", 0)  # the full ordered probe list is wanted here; tests/test_gpu_round3.py covers the lazy selection
     q = make_dataset(nq, dim, max(nlist // 4, 1), 3131, normalize=(metric == 1), uniform=uniform)
     top_k = 10
     dev = torch.device("cuda", 0)

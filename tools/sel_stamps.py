@@ -34,6 +34,13 @@ if os.environ.get("SEL_MODE") == "2":
     order = np.argsort(st)
     print("start of WG #0,256,512,768,1023 in start order:", st[order][[0, 256, 512, 768, 1023]])
     sys.exit(0)
+if os.environ.get("SEL_MODE") == "4":  # -DRBQ_SEL_STAMPS=4: sub-phases of the lazy branch, 128-cycle units
+    for t, nme in enumerate(["approx sort", "certain members (z0)", "head scoring", "T_ub", "classification", "todo scoring", "membership+compaction+sort"]):
+        if t >= 6:
+            break
+        c = ((v >> np.uint64(10 * t)) & np.uint64(0x3ff)).astype(np.float64) * 128
+        print("%-28s mean %7.0f cycles  p99 %7.0f" % (nme, c.mean(), np.percentile(c, 99)))
+    sys.exit(0)
 names = ["stage row+q", "radix select", "shortlist", "canonical", "sort", "probe+stream"]
 tot = 0
 for t, n in enumerate(names):
