@@ -567,7 +567,10 @@ def main():
         return {"kernel": "k_scan (product configuration: exact block-level bound ON)",
                 "avg_launch_ms": ms, "launches": prof["scan_launches"],
                 "algorithmic_bytes_per_launch": alg, "bytes_requested_per_launch": req, "bytes_requested_by_array": parts,
-                "block_skip_frac": 1.0 - c["code_blocks"] / max(c["stream_entries"], 1),
+                # probed blocks whose codes were never fetched (vectors_probed / 32: lists proved skipped as a whole by the probe
+                # selection never enter the stream, so the stream-entry count is no longer the number of probed blocks)
+                "block_skip_frac": 1.0 - c["code_blocks"] / max(c["vectors_probed"] / 32.0, 1.0),
+                "stream_entries_per_launch": c["stream_entries"] / max(steps, 1),
                 "frac": req / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "algorithmic_over_time_GBs": alg / (ms * 1e-3) / 1e9 if ms > 0 else None,
                 "note": "bytes_requested = what the kernel asked the memory system for in these launches (its own counters: "

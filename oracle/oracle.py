@@ -18,7 +18,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "librbq_ref.so")
+        path = os.environ.get("RBQ_REF_LIB") or os.path.join(_HERE, "librbq_ref.so")  # (override: the sanitizer build)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

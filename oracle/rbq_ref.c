@@ -674,7 +674,7 @@ size_t ref_select_probes(const rbq_header* h, const rbq_list_view* lists, const 
                                              : ref_dot(rq, lists[c].centroid, D);
         int32_t k = total_key(s);
         if (h->metric == RBQ_METRIC_IP) k = ~k; /* descending score: b.total_cmp(a) */
-        keys[c] = ((int64_t)k << 32) | (int64_t)(uint32_t)c;
+        keys[c] = (int64_t)(((uint64_t)(uint32_t)k << 32) | (uint64_t)(uint32_t)c); /* (the bit pattern of k * 2^32 + c; no shift of a negative value) */
     }
     size_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
     if (nprobe > nl) nprobe = nl;

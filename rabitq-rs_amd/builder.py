@@ -17,7 +17,7 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "csrc", "librbq_build.so")
+        path = os.environ.get("RBQ_BUILD_LIB") or os.path.join(_HERE, "csrc", "librbq_build.so")  # (override: the sanitizer build)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(path)

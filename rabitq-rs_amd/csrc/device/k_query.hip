@@ -2,6 +2,8 @@
 // (rotate + constants + LUT), the centroid-ranking GEMMs, probe selection and the MSTG probe list.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "launch.hpp"
 #include "query_kernels.hpp"
 #include "rank_mfma.hpp"
@@ -109,6 +111,10 @@ hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) 
     const size_t rowsN = RBQ_SEL_ROWS * ((size_t)p.D + 8) * 4 + 16;
     g.stage_rows = (p.lazy && lds + rowsN <= 64 * 1024) ? (uint32_t)RBQ_SEL_ROWS : 0u;
     if (g.stage_rows) lds += rowsN;
+    {   // diagnostic: extra dynamic LDS per workgroup (occupancy experiments)
+        static const size_t pad = [] { const char* e = std::getenv("RBQ_SEL_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+        lds += pad;
+    }
     if (p.nlist <= 4096) return launch_select_rm<2>(p, g, lds, device, s);
     if (g.row_in_lds) return launch_select_rm<1>(p, g, lds, device, s);
     return launch_select_rm<0>(p, g, lds, device, s);

@@ -489,6 +489,73 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { // same DPP patte
     return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+//   octets: 8 lanes per list straight from global memory, one per accumulator (4-byte loads, the 8 lanes of a list read 32
+//           contiguous bytes per step), 32 lists per round, 30 loads in flight per lane: a third of a pair round's time for
+//           up to 32 lists — the middle ground between `staged` (<= 8 lists) and `pairs` (> 64).
+template <typename IdxFn>
+__device__ __forceinline__ void canon_score_octets(uint64_t* keys, const float* qrot, const float* __restrict__ cent, uint32_t D, int metric,
+                                                   float* grow, uint32_t m, uint32_t tid, IdxFn idx_of) {
+    const uint32_t a = tid & 7u, grp = tid >> 3, Dmain = D & ~7u;
+    for (uint32_t i0 = 0; i0 < m; i0 += kThreads / 8) {
+        const uint32_t j = i0 + grp;
+        if (j < m) { // uniform per 8-lane group
+            const uint32_t e = idx_of(j);
+            const uint32_t cid = (uint32_t)keys[e];
+            const float* c = cent + (size_t)cid * D;
+            float acc = 0.0f, acc2 = 0.0f;
+            // explicit two-phase steps (all loads of a batch, then its adds in order): left to itself hipcc waits for every
+            // load in front of its add
+            constexpr int KB = 24;
+            for (uint32_t base = a; base < Dmain; base += 8 * KB) {
+                float cv[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) cv[k] = base + 8u * k < Dmain ? c[base + 8u * k] : 0.0f;
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    if (base + 8u * k < Dmain) {
+                        const float qv = qrot[base + 8u * k];
+                        if (metric == 0) {
+                            const float d = qv - cv[k];
+                            const float p = d * d;
+                            acc = acc + p;
+                        } else {
+                            const float p = qv * cv[k];
+                            const float d = qv - cv[k];
+                            const float r2 = d * d;
+                            acc = acc + p;
+                            acc2 = acc2 + r2;
+                        }
+                    }
+                }
+            }
+            float sum = 0.0f, sum2 = 0.0f;
+            if (Dmain) {
+                sum = -0.0f; sum2 = -0.0f;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    sum = sum + __shfl(acc, l, 8);
+                    sum2 = sum2 + __shfl(acc2, l, 8);
+                }
+            }
+            for (uint32_t i = Dmain; i < D; ++i) { // scalar tail
+                const float qv = qrot[i], cv = c[i];
+                const float d = qv - cv;
+                const float r2 = d * d;
+                if (metric == 0) sum = sum + r2;
+                else {
+                    const float p = qv * cv;
+                    sum = sum + p;
+                    sum2 = sum2 + r2;
+                }
+            }
+            if (a == 0) {
+                keys[e] = make_key(sum, cid, metric);
+                if (metric == 1) grow[cid] = sum2;
+            }
+        }
+    }
+}
+
 // ascending sort of keys[0..n) (distinct keys; entries n..cap2-1 must be ~0 for the bitonic branch)
 __device__ __forceinline__ void sort_keys(uint64_t* keys, uint32_t n, uint32_t cap2, uint32_t tid) {
     if (n <= 2 * kThreads) {
@@ -970,8 +1037,13 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                     const uint32_t m = s_need;
                     if (m) { // uniform
                         auto todo_idx = [&](uint32_t j) { return hist[j]; };
-                        if (G.stage_rows && m <= 4u * G.stage_rows) canon_score_staged(keys, qrot, P.cent, D, metric, grow, m, tid, rows, G.stage_rows, todo_idx);
-                        else { canon_score_pairs(keys, qrot, P.cent, D, metric, grow, m, tid, todo_idx); __threadfence_block(); __syncthreads(); }
+                        if (G.stage_rows && m <= 2u * G.stage_rows) canon_score_staged(keys, qrot, P.cent, D, metric, grow, m, tid, rows, G.stage_rows, todo_idx);
+                        else {
+                            if (m <= 64u) canon_score_octets(keys, qrot, P.cent, D, metric, grow, m, tid, todo_idx);
+                            else canon_score_pairs(keys, qrot, P.cent, D, metric, grow, m, tid, todo_idx);
+                            __threadfence_block();
+                            __syncthreads();
+                        }
                     }
                     LSTAMP(5);
                     // membership: certain, or a scored zone list with fewer than nprobe - z0 smaller zone keys (the zone
@@ -1263,7 +1335,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
     if (tid == 0) {
         unsigned long long pk = 0;
 #if RBQ_SEL_STAMPS == 2
-        pk = ((ts[0] & 0xffffffffull) << 32) | ((ts[6] - ts[0]) & 0xffffffffull); // absolute start | duration
+        pk = (((ts[0] >> 4) & 0xffffffffull) << 32) | ((ts[6] - ts[0]) & 0xffffffffull); // absolute start (16-cycle units) | duration
         P.nvec[q] = pk;
 #elif RBQ_SEL_STAMPS == 3
         P.nvec[q] = ((unsigned long long)m_scan << 32) | s_cnt; // lists scanned | shortlist size

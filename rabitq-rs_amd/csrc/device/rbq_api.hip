@@ -27,8 +27,12 @@
 
 #include "rbq.h"
 #include "launch.hpp"
+#include "../host/rbq_host_logic.hpp"
 
 using namespace rbq;
+using rbq_host::ListSrc;
+using rbq_host::OutPack;
+using rbq_host::align_up;
 
 namespace {
 
@@ -69,7 +73,6 @@ struct DeviceGuard {
 };
 
 uint32_t floor_log2_u32(uint32_t x) { uint32_t r = 0; while (x >>= 1) ++r; return r; }
-size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct DevBuf {
     void* p = nullptr;
@@ -432,18 +435,6 @@ int wrap_and_replicate(Replica* first, const std::vector<int>& devs, rbq_index**
 }
 
 // ---- create / load: reference layout in, device layout out --------------------------------------------------------
-// One ClusterData as byte ranges (an RBQ1 stream has no alignment; rbq_list_view arrays are viewed the same way).
-struct ListSrc {
-    const uint8_t* centroid = nullptr; // D f32
-    uint64_t n = 0;
-    const uint8_t* ids = nullptr;        // n u64
-    const uint8_t* batch_data = nullptr; // ceil(n/32) records of D*4 + 384 bytes
-    const uint8_t* ex = nullptr;         // n packed ex codes, `ex_stride` bytes apart
-    size_t ex_stride = 0;
-    const uint8_t* fadd = nullptr;       // n f32
-    const uint8_t* fres = nullptr;       // n f32
-};
-
 int create_from_sources(const rbq_header* hdr, const std::vector<ListSrc>& lists, int dev, Replica** out) {
     DeviceGuard g(dev);
     if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
@@ -1072,15 +1063,6 @@ int check_query_args(const rbq_index* h, uint32_t query_dim) {
     return RBQ_OK;
 }
 
-// layout of one sub-batch's results in the packed device / pinned buffers
-struct OutPack {
-    size_t o_ids, o_scores, o_counts, o_diag, total;
-    OutPack(uint64_t n, uint32_t top_k, bool diag) {
-        o_ids = 0; o_scores = align_up(n * top_k * 8, 16); o_counts = o_scores + align_up(n * top_k * 4, 16);
-        o_diag = o_counts + align_up(n * 4, 16); total = o_diag + (diag ? n * sizeof(rbq_diag) : 0);
-    }
-};
-
 // rbq_search_batch on ONE replica.  The batch is cut into sub-batches of (by default) 1024 queries that travel through
 // up to six lanes (stream + workspace + pinned staging each), so the stages of neighbouring sub-batches overlap on the
 // GPU exactly like bench.py's device-resident batches do, and the host stages sub-batch j+1 while j runs.
@@ -1100,10 +1082,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     double t_attr = 0, t_ws = 0, t_stage = 0, t_enq = 0, t_wait = 0, t_out = 0;
     auto tick = [&](clk::time_point& t0, double& acc) { if (trace) { const auto t1 = clk::now(); acc += std::chrono::duration<double, std::micro>(t1 - t0).count(); t0 = t1; } };
     clk::time_point tp = clk::now();
-    // sub-batch: 1024 queries (also bounds the nq x nlist score matrix per lane); a call (or replica shard) of fewer than
-    // 2048 queries is cut in two, so that the H2D copy and the kernels of its halves overlap on two lanes
-    uint64_t SB = ix->host_subbatch ? ix->host_subbatch : (nq >= 2048 ? 1024 : std::max<uint64_t>(256, (nq + 1) / 2));
-    SB = std::min<uint64_t>(SB, nq);
+    const uint64_t SB = rbq_host::subbatch_size(nq, ix->host_subbatch); // 1024; a call below 2048 queries is cut in two
     const uint64_t nsub = (nq + SB - 1) / SB;
     const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 6u);
     const bool in_pinned = is_pinned_host_range(queries, nq * query_dim * 4);
@@ -1267,116 +1246,15 @@ uint32_t rbq_index_device_count(const rbq_index* h) { return h ? (uint32_t)h->re
 // ---- RBQ1 v3 reader: load_from_reader, src/ivf.rs:1484-1702 --------------------------------------
 } // extern "C"
 namespace {
-struct Reader {
-    const uint8_t* p; size_t len, off = 0;
-    bool take(void* dst, size_t n) { if (off + n > len || off + n < off) return false; std::memcpy(dst, p + off, n); off += n; return true; }
-    const uint8_t* view(size_t n) { if (off + n > len || off + n < off) return nullptr; const uint8_t* r = p + off; off += n; return r; }
-};
-uint32_t crc32_ieee(const uint8_t* p, size_t n) {
-    static uint32_t table[8][256];
-    static std::once_flag once;
-    std::call_once(once, [] {
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[0][i] = c;
-        }
-        for (uint32_t i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xff];
-    });
-    uint32_t crc = ~0u;
-    while (n >= 8) {
-        uint32_t a, b;
-        std::memcpy(&a, p, 4); std::memcpy(&b, p + 4, 4);
-        a ^= crc;
-        crc = table[7][a & 0xff] ^ table[6][(a >> 8) & 0xff] ^ table[5][(a >> 16) & 0xff] ^ table[4][a >> 24] ^
-              table[3][b & 0xff] ^ table[2][(b >> 8) & 0xff] ^ table[1][(b >> 16) & 0xff] ^ table[0][b >> 24];
-        p += 8; n -= 8;
-    }
-    while (n--) crc = table[0][(crc ^ *p++) & 0xff] ^ (crc >> 8);
-    return ~crc;
-}
-
 int load_rbq1_impl(const void* bytes, size_t len, int n_devices, const int* devices, rbq_index** out) {
     if (!out) return fail(RBQ_INVALID_CONFIG, "null out pointer");
     *out = nullptr;
-    if (!bytes) return fail(RBQ_IO, "null buffer");
-    Reader r{(const uint8_t*)bytes, len};
-    auto eof = [] { return fail(RBQ_IO, "failed to fill whole buffer"); };
-    char magic[4];
-    if (!r.take(magic, 4)) return eof();
-    if (std::memcmp(magic, "RBQ1", 4) != 0) return fail(RBQ_INVALID_PERSISTENCE, "unrecognized file header");
-    uint32_t version;
-    if (!r.take(&version, 4)) return eof();
-    if (version != 3) return fail(RBQ_INVALID_PERSISTENCE, "unsupported index format version (expected V3 with unified memory layout)");
     rbq_header h;
-    std::memset(&h, 0, sizeof h);
-    uint8_t tags[4];
-    if (!r.take(&h.dim, 4)) return eof();
-    if (h.dim == 0) return fail(RBQ_INVALID_PERSISTENCE, "dimension must be positive");
-    if (!r.take(&h.padded_dim, 4)) return eof();
-    if (h.padded_dim < h.dim) return fail(RBQ_INVALID_PERSISTENCE, "padded_dim must be >= dim");
-    if (!r.take(tags, 4)) return eof();
-    if (tags[0] > 1) return fail(RBQ_INVALID_PERSISTENCE, "unknown metric tag");
-    if (tags[1] > 1) return fail(RBQ_INVALID_PERSISTENCE, "unknown rotator type tag");
-    if (tags[2] > 16) return fail(RBQ_INVALID_PERSISTENCE, "ex_bits out of range");
-    if (tags[3] == 0 || tags[3] > 16) return fail(RBQ_INVALID_PERSISTENCE, "total_bits out of range");
-    if ((uint8_t)(tags[3] - 1) != tags[2]) return fail(RBQ_INVALID_PERSISTENCE, "total_bits does not match ex_bits");
-    h.metric = tags[0]; h.rotator = tags[1]; h.ex_bits = tags[2];
-    uint64_t expected_vectors, cluster_count, rot_len;
-    if (!r.take(&expected_vectors, 8) || !r.take(&cluster_count, 8) || !r.take(&rot_len, 8)) return eof();
-    const uint8_t* blob = r.view(rot_len);
-    if (!blob) return eof();
-    h.rotator_blob = blob; h.rotator_len = rot_len; h.n_lists = cluster_count; h.n_vectors = expected_vectors;
-    { // DynamicRotator::deserialize length checks (src/rotation.rs:213-219,491-497)
-        const uint64_t want = h.rotator == RBQ_ROTATOR_FHT_KAC ? (uint64_t)4 * h.padded_dim / 8 : (uint64_t)h.padded_dim * h.padded_dim * 4;
-        if (rot_len != want)
-            return fail(RBQ_INVALID_PERSISTENCE, h.rotator == RBQ_ROTATOR_FHT_KAC ? "FHT rotator flip bits length mismatch" : "rotator matrix length mismatch");
-    }
-    if (cluster_count > (len / 8)) return eof(); // every cluster costs >= 8 bytes; guards the allocation below
-    const size_t D = h.padded_dim, stride = D * 4 + 384;
-    const size_t exb_expected = h.ex_bits ? D * h.ex_bits / 8 : 0;
-    // the lists are used where they lie in the stream (byte-addressed): nothing is copied on the host but the chunk staging
-    std::vector<ListSrc> lists(cluster_count);
-    uint64_t actual = 0;
-    for (uint64_t c = 0; c < cluster_count; ++c) {
-        ListSrc& L = lists[c];
-        L.centroid = r.view(D * 4);
-        if (!L.centroid) return eof();
-        uint64_t n;
-        if (!r.take(&n, 8)) return eof();
-        if (n > 1000000) return fail(RBQ_INVALID_PERSISTENCE, "cluster size exceeds reasonable limits - possible corruption");
-        L.n = n;
-        L.ids = r.view(n * 8);
-        if (!L.ids) return eof();
-        uint64_t blen;
-        if (!r.take(&blen, 8)) return eof();
-        if (blen != ((n + 31) / 32) * stride)
-            return fail(RBQ_INVALID_PERSISTENCE, "batch_data length mismatch - possible corruption or version incompatibility");
-        L.batch_data = r.view(blen);
-        if (!L.batch_data) return eof();
-        L.ex_stride = exb_expected + 8; // every packed code carries a u64 length prefix
-        for (uint64_t v = 0; v < n; ++v) {
-            uint64_t el;
-            if (!r.take(&el, 8)) return eof();
-            if (el != exb_expected)
-                return fail(RBQ_INVALID_PERSISTENCE, "ex_code_packed length mismatch - possible corruption or version incompatibility");
-            const uint8_t* e = r.view(el);
-            if (!e) return eof();
-            if (v == 0) L.ex = e;
-        }
-        L.fadd = r.view(n * 4);
-        L.fres = r.view(n * 4);
-        if (!L.fadd || !L.fres) return eof();
-        if (!r.view(n * 4) || !r.view(n * 4)) return eof(); // delta, vl: reconstruction only
-        actual += n;
-    }
-    if (actual != expected_vectors) return fail(RBQ_INVALID_PERSISTENCE, "vector count metadata mismatch");
-    const size_t body_end = r.off;
-    uint32_t stored;
-    if (!r.take(&stored, 4)) return eof();
-    if (crc32_ieee((const uint8_t*)bytes + 8, body_end - 8) != stored) return fail(RBQ_INVALID_PERSISTENCE, "checksum mismatch");
-    int rc = validate_header(&h); // what this build cannot serve (ex_bits outside {0,2,6}, padded_dim > 2048 ...)
+    std::vector<ListSrc> lists; // byte ranges of the stream: nothing is copied on the host but the chunk staging
+    std::string detail;
+    int rc = rbq_host::rbq1_parse(bytes, len, &h, &lists, &detail); // load_from_reader's validation, CRC included
+    if (rc) return fail(rc, detail);
+    rc = validate_header(&h); // what this build cannot serve (ex_bits outside {0,2,6}, padded_dim > 2048 ...)
     if (rc) return rc;
     std::vector<int> devs;
     if ((rc = resolve_devices(n_devices, devices, devs))) return rc;
@@ -1508,7 +1386,8 @@ int rbq_search_batch(const rbq_index* ch, const float* queries, uint64_t nq, uin
     struct Latch { std::mutex mu; std::condition_variable cv; size_t left; } latch;
     latch.left = R - 1;
     auto shard = [&](size_t r) {
-        const uint64_t q0 = r * nq / R, q1 = (r + 1) * nq / R;
+        uint64_t q0, q1;
+        rbq_host::shard_range(r, R, nq, &q0, &q1);
         try {
             rcs[r] = search_host(h->reps[r], queries + q0 * query_dim, q1 - q0, query_dim, top_k, nprobe, filter_words, filter_nbits,
                                  out_ids + q0 * top_k, out_scores + q0 * top_k, out_counts + q0, diag ? diag + q0 : nullptr);

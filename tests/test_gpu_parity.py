@@ -542,8 +542,9 @@ def test_large_nprobe_select_paths(nprobe):
 
 @pytest.mark.parametrize("top_k", [63, 64, 500, 4096, 16384])
 def test_large_top_k(top_k):
-    """top_k < 64 keeps the heap in registers, top_k >= 64 in LDS (exact BinaryHeap emulation, one lane); 16384 is the
-    documented limit and exceeds the number of probed candidates here (counts < top_k, NaN / u64::MAX padding)."""
+    """top_k <= 256 keeps the top-k in the replay wave's registers (sorted run / RankRun; RegHeap after a tie), above that
+    the exact BinaryHeap emulation runs on an LDS array from the first candidate (one lane); 16384 exceeds the number of
+    probed candidates here (counts < top_k, NaN / u64::MAX padding)."""
     data, built = build_index(n=6000, dim=64, nlist=24, total_bits=7, seed=71)
     idx = rq.IvfRabitqIndex.from_built(built)
     q = make_dataset(12, 64, 6, 72)

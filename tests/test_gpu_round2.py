@@ -347,9 +347,12 @@ def test_profile_traffic_counters():
         blocks += int(((sizes[probes] + 31) // 32).sum())
         vectors += int(sizes[probes].sum())
     assert c0["queries"] == 200 and c1["queries"] == 200
-    assert c0["vectors_probed"] == vectors == c1["vectors_probed"] and bytes0 == vectors * (D // 8 + 12) == bytes1
+    assert c0["vectors_probed"] == vectors and bytes0 == vectors * (D // 8 + 12)
+    # bound on = lazy probe selection on: lists proved skipped as a whole never enter the stream, and without diagnostics
+    # the profile counts the APPROXIMATE probe set (boundary lists may differ from the exact one by a list or two)
+    assert abs(c1["vectors_probed"] - vectors) <= 0.02 * vectors and bytes1 == c1["vectors_probed"] * (D // 8 + 12)
     assert c0["stream_entries"] == blocks and c0["code_blocks"] == blocks and c0["meta_blocks"] == blocks
-    assert c1["stream_entries"] == blocks and 0 < c1["code_blocks"] <= blocks  # (how much the bound prunes depends on the data)
+    assert c1["stream_entries"] <= blocks and 0 < c1["code_blocks"] <= c1["stream_entries"]  # (how much is pruned depends on the data)
     assert c0["ex_evals"] >= c1["ex_evals"] > 0
     idx.close()
 
@@ -428,7 +431,9 @@ def test_full_size_baseline_configs_properties(name, n, dim, nlist, bits, metric
       * the host entry point (pageable buffers, sub-batch pipeline, diagnostics) returns the device path's bits,
       * results are well-formed: counts == top_k, distances ascending (L2) / scores descending (IP), ids distinct and
         inside the index; recall@10 against exact f32 brute force is at the level bench.py reports.
-    (bench.py itself compares two 1024-query batches of the full-size cfg3 index with the oracle on every run.)"""
+    And, since round 3, the oracle itself on the first 128 queries: the CPU build of the same index (arrays byte-identical to
+    the device encoder's) searched by oracle.search_batch — ids, counts and SearchDiagnostics exactly, scores at 1e-4.
+    (bench.py also compares two 1024-query batches of the full-size cfg3 index with the oracle on every run.)"""
     import torch
     import bench
     dev = torch.device("cuda", 0)
@@ -461,8 +466,19 @@ def test_full_size_baseline_configs_properties(name, n, dim, nlist, bits, metric
     gt = bench.exact_topk(torch, x, q, top_k, metric).cpu().numpy()
     rec = bench.recall_of(ids, gt, top_k)
     assert rec > (0.93 if bits == 3 else 0.95), rec
+    # the oracle at full size: CPU build (seconds on the box's cores) + 128 queries
+    built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), bits, metric, 1,
+                                           20260104, True)
     del x
     torch.cuda.empty_cache()
+    nor = 128
+    rc, oids, osc, ocnt, odiag = oracle.search_batch(built, qh[:nor], top_k, nprobe, want_diag=True)
+    assert rc == 0
+    assert np.array_equal(ids[:nor], oids) and np.array_equal(cnt[:nor], ocnt), f"{name}: ids differ from the oracle at full size"
+    np.testing.assert_allclose(sc[:nor], osc, rtol=RTOL, atol=0)
+    gid, gsc, gcnt, gdiag = idx.batch_search_raw(qh[:nor], rq.SearchParams(top_k, nprobe), want_diag=True)
+    assert np.array_equal(gid, oids) and np.array_equal(gdiag, odiag), f"{name}: SearchDiagnostics differ from the oracle at full size"
+    del built
     # batch independence: permuted batch, a ragged sub-batch, single queries
     perm = np.random.default_rng(5).permutation(batch)
     pid, psc, _ = dev_search(q[torch.from_numpy(perm).to(dev)].contiguous(), batch)
@@ -473,7 +489,8 @@ def test_full_size_baseline_configs_properties(name, n, dim, nlist, bits, metric
         oid, osc, _ = dev_search(q[i:i + 1].contiguous(), 1)
         assert np.array_equal(oid[0], ids[i]) and np.array_equal(osc[0].view(np.uint32), sc[i].view(np.uint32))
     # diagnostic switches: same bits, different work
-    for opt, val, back in (("block_bound", 0, 1), ("exact_rank", 1, 0), ("f32_rank", 1, 0), ("exact_heap", 1, 0), ("wg_prep", 1, 0)):
+    for opt, val, back in (("block_bound", 0, 1), ("exact_rank", 1, 0), ("f32_rank", 1, 0), ("exact_heap", 1, 0), ("wg_prep", 1, 0),
+                           ("lazy_select", 0, 1)):
         idx.set_option(opt, val)
         nq_o = 512 if opt == "exact_rank" else batch  # (the all-pairs canonical ranking is the slow one)
         o_ids, o_sc, o_cnt = dev_search(q[:nq_o].contiguous(), nq_o)

@@ -1,0 +1,168 @@
+"""CPU sanitizer runs ("race detection / sanitizers"; no GPU-side sanitizer exists on this pool): everything that
+runs on the CPU — the oracle, the CPU index builder and the GPU-free host logic of librbq.so (RBQ1 parser / validator, CRC,
+result packing, shard arithmetic) — built with -fsanitize=address,undefined (__graft_entry__.build_sanitized) and driven
+(1) through the oracle known-answer suite and the ABI tests in a child interpreter that preloads the sanitizer runtimes,
+(2) by the RBQ1 mutation fuzzer against the sanitized parser, every byte of every list view read back."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, build_index
+
+
+def _san_env():
+    import __graft_entry__ as g
+    out = g.build_sanitized()
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    env = dict(os.environ, LD_PRELOAD=f"{asan}:{ubsan}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:allocator_may_return_null=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", RBQ_REF_LIB=os.path.join(out, "librbq_ref_san.so"),
+               RBQ_BUILD_LIB=os.path.join(out, "librbq_build_san.so"), RBQ_HOSTCHECK_LIB=os.path.join(out, "librbq_hostcheck_san.so"),
+               OMP_NUM_THREADS="4")
+    return env
+
+
+def test_oracle_and_builder_suites_under_asan_ubsan():
+    """tests/test_oracle_kat.py (every known-answer vector of the reference, the three accumulate formulations, rotations,
+    the naive-vs-fastscan tolerances, filter / error semantics, the RBQ1 facts) and tests/test_abi.py with the sanitized
+    oracle and builder: no report from either sanitizer (abort_on_error / halt_on_error end the child with a signal)."""
+    env = _san_env()
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_kat.py"), os.path.join(ROOT, "tests", "test_abi.py"),
+                          "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert "passed" in out.stdout and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
+
+
+_CHILD = r"""
+import ctypes as C, os, sys, zlib
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import conftest
+L = C.CDLL(os.environ["RBQ_HOSTCHECK_LIB"])
+L.rbq_hostcheck_parse.restype = C.c_int
+L.rbq_hostcheck_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+L.rbq_hostcheck_crc32.restype = C.c_uint32
+L.rbq_hostcheck_crc32.argtypes = [C.c_void_p, C.c_size_t]
+L.rbq_hostcheck_outpack.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
+L.rbq_hostcheck_shard.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+L.rbq_hostcheck_subbatch.restype = C.c_uint64
+L.rbq_hostcheck_subbatch.argtypes = [C.c_uint64, C.c_uint64]
+
+def parse(blob):
+    buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))   # exact-size heap copy: a read past the end is an ASan report
+    det = C.create_string_buffer(256); nl, nv, cs = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = L.rbq_hostcheck_parse(buf, len(blob), det, 256, C.byref(nl), C.byref(nv), C.byref(cs))
+    return rc, det.value.decode(), nl.value, nv.value
+
+outcomes = {}
+for seed in range(%(first)d, %(last)d):
+    rng = np.random.default_rng(seed)
+    bits, metric, rot = int(rng.choice([1, 3, 7])), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    dim = int(rng.choice([16, 48, 64, 100])) if rot == 1 else 32
+    n = int(rng.integers(40, 400))
+    data, built = conftest.build_index(n=n, dim=dim, nlist=int(rng.integers(1, 6)), total_bits=bits, metric=metric, rotator=rot, seed=seed)
+    blob = bytearray(built.save_rbq1())
+    rc, det, nl, nv = parse(blob)
+    assert rc == 0 and nv == n and nl == built.n_lists, (rc, det, nl, nv)
+    assert L.rbq_hostcheck_crc32((C.c_uint8 * (len(blob) - 12)).from_buffer_copy(bytes(blob[8:-4])), len(blob) - 12) == zlib.crc32(bytes(blob[8:-4]))
+    for m in range(40):
+        bad = bytearray(blob)
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            off = int(rng.integers(4, min(64, len(bad) - 12)))
+            vals = [0, 1, 0xff, 0xffff, 2**31, 2**32 - 1, 2**63, 2**64 - 1]
+            bad[off:off + 8] = vals[int(rng.integers(0, len(vals)))].to_bytes(8, "little")
+        elif kind == 1:
+            bad[int(rng.integers(0, len(bad) - 4))] = int(rng.integers(0, 256))
+        elif kind == 2:
+            off = int(rng.integers(8, len(bad) - 20))
+            bad[off:off + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        elif kind == 3:
+            bad = bad[:int(rng.integers(8, len(bad) - 4))] + bad[-4:]
+        else:
+            off = int(rng.integers(8, len(bad) - 4))
+            bad[off:off] = bytes(rng.integers(0, 256, int(rng.integers(1, 64)), dtype=np.uint8))
+        if len(bad) >= 12:
+            bad[-4:] = zlib.crc32(bytes(bad[8:-4])).to_bytes(4, "little")   # CRC made valid again: the parser goes past it
+        rc, det, nl, nv = parse(bad)
+        outcomes[(rc, det)] = outcomes.get((rc, det), 0) + 1
+# result packing / shard / sub-batch arithmetic
+o = (C.c_uint64 * 5)()
+for n_, k_, d_ in ((1, 1, 0), (1024, 10, 1), (777, 100, 1), (4096, 16384, 0)):
+    L.rbq_hostcheck_outpack(n_, k_, d_, o)
+    assert o[0] == 0 and o[1] >= n_ * k_ * 8 and o[2] >= o[1] + n_ * k_ * 4 and o[3] >= o[2] + n_ * 4 and o[4] == o[3] + (n_ * 24 if d_ else 0)
+    assert all(v %% 16 == 0 for v in o[:4])
+s = (C.c_uint64 * 2)()
+for R in (1, 2, 3, 8, 16):
+    for nq in (R * 2, 333, 8192, 2**40 + 7):
+        prev = 0
+        for r in range(R):
+            L.rbq_hostcheck_shard(r, R, nq, s)
+            assert s[0] == prev and s[1] >= s[0]
+            prev = s[1]
+        assert prev == nq
+for nq in (1, 2, 255, 256, 512, 1023, 1024, 2047, 2048, 100000):
+    sb = L.rbq_hostcheck_subbatch(nq, 0)
+    assert 1 <= sb <= max(nq, 1) and sb <= 1024 and (nq < 2048 or sb == 1024)
+print("outcomes", len(outcomes), sum(outcomes.values()))
+for k, v in sorted(outcomes.items(), key=lambda kv: -kv[1])[:8]:
+    print("  %%5d rc=%%d %%s" %% (v, k[0], k[1]))
+"""
+
+
+def test_rbq1_parser_fuzzed_under_asan_ubsan():
+    """The RBQ1 mutation fuzzer (tests/diag/fuzz_rbq1.py's mutations: extreme header fields, flipped bytes, replaced
+    runs, truncation, insertion — each with the CRC made valid again) against the sanitized parser.  Every accepted
+    stream has every byte of every list view read back (an out-of-range view would be an ASan report); result packing,
+    shard and sub-batch arithmetic of rbq_search_batch are exercised in the same build."""
+    env = _san_env()
+    code = _CHILD % {"root": ROOT, "first": 0, "last": 12}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "outcomes" in out.stdout and "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr
+
+
+def test_sanitized_parser_agrees_with_the_product_library():
+    """The product library parses RBQ1 with the same header (csrc/host/rbq_host_logic.hpp): for corrupted streams both
+    return the same error code and message (no GPU needed: every case fails before the device stage)."""
+    import rabitq_rs_amd as rq  # noqa: F401
+    from rabitq_rs_amd import index as ix
+    import __graft_entry__ as g
+    out = g.build_sanitized()
+    # the unsanitized build of the same shim is not needed: compare through a child that loads the sanitized one
+    data, built = build_index(n=300, dim=64, nlist=3, total_bits=7, seed=9)
+    blob = bytearray(built.save_rbq1())
+    cases = []
+    for off, val in ((0, b"XBQ1"), (4, (7).to_bytes(4, "little")), (8, (0).to_bytes(4, "little")), (20, (2**40).to_bytes(8, "little")),
+                     (len(blob) - 4, b"\x00\x00\x00\x00")):
+        bad = bytearray(blob)
+        bad[off:off + len(val)] = val
+        cases.append(bytes(bad))
+    cases.append(bytes(blob[:len(blob) // 2]))
+    prod = []
+    for bad in cases:
+        h = C.c_void_p()
+        buf = (C.c_uint8 * len(bad)).from_buffer_copy(bad)
+        rc = ix.lib().rbq_index_load_rbq1(buf, len(bad), 1, None, C.byref(h))
+        prod.append((rc, ix._detail()))
+        assert rc != 0
+    env = _san_env()
+    code = (
+        "import ctypes as C, os, sys\n"
+        "L = C.CDLL(os.environ['RBQ_HOSTCHECK_LIB'])\n"
+        "L.rbq_hostcheck_parse.restype = C.c_int\n"
+        "L.rbq_hostcheck_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]\n"
+        "for line in sys.stdin.read().split():\n"
+        "    bad = bytes.fromhex(line)\n"
+        "    det = C.create_string_buffer(256)\n"
+        "    rc = L.rbq_hostcheck_parse((C.c_uint8 * len(bad)).from_buffer_copy(bad), len(bad), det, 256, None, None, None)\n"
+        "    print(rc, det.value.decode())\n")
+    res = subprocess.run([sys.executable, "-c", code], env=env, input="\n".join(c.hex() for c in cases), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = [(int(l.split(" ", 1)[0]), l.split(" ", 1)[1] if " " in l else "") for l in res.stdout.strip().splitlines()]
+    assert got == prod, (got, prod)

@@ -29,8 +29,8 @@ if os.environ.get("SEL_MODE") == "3":
     sys.exit(0)
 if os.environ.get("SEL_MODE") == "2":
     st = (v >> np.uint64(32)).astype(np.int64); du = (v & np.uint64(0xffffffff)).astype(np.int64)
-    st = (st - st.min()) & 0xffffffff
-    print("starts: min 0 p50 %d p90 %d max %d ; duration mean %d p99 %d ; last end %d" % (np.percentile(st, 50), np.percentile(st, 90), st.max(), du.mean(), np.percentile(du, 99), (st + du).max()))
+    st = ((st - st.min()) & 0xffffffff) * 16
+    print("starts: min 0 p50 %d p90 %d max %d ; duration mean %d p99 %d max %d ; last end %d" % (np.percentile(st, 50), np.percentile(st, 90), st.max(), du.mean(), np.percentile(du, 99), du.max(), (st + du).max()))
     order = np.argsort(st)
     print("start of WG #0,256,512,768,1023 in start order:", st[order][[0, 256, 512, 768, 1023]])
     sys.exit(0)
@@ -39,12 +39,12 @@ if os.environ.get("SEL_MODE") == "4":  # -DRBQ_SEL_STAMPS=4: sub-phases of the l
         if t >= 6:
             break
         c = ((v >> np.uint64(10 * t)) & np.uint64(0x3ff)).astype(np.float64) * 128
-        print("%-28s mean %7.0f cycles  p99 %7.0f" % (nme, c.mean(), np.percentile(c, 99)))
+        print("%-28s mean %7.0f cycles  p99 %7.0f  max %7.0f" % (nme, c.mean(), np.percentile(c, 99), c.max()))
     sys.exit(0)
 names = ["stage row+q", "radix select", "shortlist", "canonical", "sort", "probe+stream"]
 tot = 0
 for t, n in enumerate(names):
     c = ((v >> np.uint64(10 * t)) & np.uint64(0x3ff)).astype(np.float64) * 256
     tot += c.mean()
-    print("%-14s mean %7.0f cycles  p99 %7.0f" % (n, c.mean(), np.percentile(c, 99)))
+    print("%-14s mean %7.0f cycles  p99 %7.0f  max %7.0f" % (n, c.mean(), np.percentile(c, 99), c.max()))
 print("total %.0f cycles; shortlist size mean (mod 16) %.1f" % (tot, (v >> np.uint64(60)).astype(np.float64).mean()))
