@@ -160,8 +160,10 @@ uint32_t rbq_index_device_count(const rbq_index* idx); /* number of replicas */
  * Errors follow search_fastscan: EMPTY_INDEX is checked before
  * DIMENSION_MISMATCH (src/ivf.rs:1761-1769); top_k == 0 returns RBQ_OK with all
  * counts 0 (:1792-1794); nprobe is clamped to [1, n_lists] (:1791).
- * Limits of this version (the reference has none): after the clamp nprobe <= 8192 and top_k <= 16384 (above 256 the
- * exact heap is an array in the LDS of one compute unit: one workgroup per CU from top_k ~ 7000), else
+ * Every nprobe (clamped to n_lists) and every top_k <= 2^20 is served.  Fast paths: nprobe <= 8192 (MFMA shortlist with
+ * its key window in LDS; above it the exact all-pairs ranking with the window in global memory), top_k <= 256 (top-k in
+ * registers), top_k <= 16384 (exact heap in the LDS of one compute unit: one workgroup per CU from top_k ~ 7000; above it
+ * the heap lives in global memory).  top_k > 2^20, or nq * top_k * 8 bytes of heap workspace > 8 GiB in one device call, is
  * RBQ_INVALID_CONFIG; nq < 2^31 per call of the device entry.
  * Re-entrant on one handle.  The batch is cut into sub-batches that are pipelined over a few streams: host
  * staging and PCIe copies of one sub-batch overlap the kernels of the others.  Buffers that are page-locked

@@ -72,15 +72,18 @@ hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s) {
     return p.big ? launch_rank_f32<1, 2>(p, grid, s) : launch_rank_f32<1, 1>(p, grid, s);
 }
 
-hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s) {
+uint32_t select_exact_np2(uint32_t nprobe) { return next_pow2(nprobe); }
+
+hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s, uint64_t* key_window) {
     const uint32_t np2 = next_pow2(p.nprobe);
-    const size_t lds = (size_t)np2 * 8 + (size_t)p.D * 4 + kThreads * 4;
+    // key_window != null: [nq][np2] u64 in global memory (nprobe > kNprobeMax)
+    const size_t lds = (key_window ? 0 : (size_t)np2 * 8) + (size_t)p.D * 4 + kThreads * 4;
     static LdsAttrCache attr; // nprobe > 4096: more than the default 64 KB of dynamic LDS
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_select), lds, device);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_select, dim3(p.nq), dim3(kThreads), lds, s, (const float*)p.scores, p.nlist, p.nprobe, np2, p.metric, p.rot,
                        p.cent, p.D, p.list_gb0, p.list_n, p.probe, p.wl, p.wl_stride, p.nstream, p.nvec, p.prof_total, p.consts,
-                       p.bsum);
+                       p.bsum, key_window);
     return hipGetLastError();
 }
 

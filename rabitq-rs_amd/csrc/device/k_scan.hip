@@ -9,6 +9,7 @@
 
 namespace rbq {
 
+#ifndef RBQ_SCAN_TU2
 hipError_t LdsAttrCache::ensure(const void* fn, size_t lds, int device) {
     if (lds <= 48 * 1024) return hipSuccess; // default dynamic-LDS limit
     const int d = device & 15;
@@ -20,6 +21,7 @@ hipError_t LdsAttrCache::ensure(const void* fn, size_t lds, int device) {
     if (e == hipSuccess) set[d].store(lds, std::memory_order_release);
     return e;
 }
+#endif
 
 namespace {
 
@@ -55,13 +57,39 @@ hipError_t launch_scan_d(const ScanParams& P, uint32_t nq, size_t lds, int devic
 
 } // namespace
 
+#ifndef RBQ_SCAN_TU2
+hipError_t launch_scan_more_dims(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                                 bool* handled); // k_scan2.hip
+
 hipError_t launch_scan(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t D = P.D, Dc = P.Dc;
-    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, P.top_k);
+    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, P.top_k, P.heap_ws == nullptr);
     if (D == Dc && D == 960) return launch_scan_d<960>(P, nq, lds, device, s, ev0, ev1);
     if (D == Dc && D == 768) return launch_scan_d<768>(P, nq, lds, device, s, ev0, ev1);
     if (D == Dc && D == 128) return launch_scan_d<128>(P, nq, lds, device, s, ev0, ev1);
-    return launch_scan_d<0>(P, nq, lds, device, s, ev0, ev1);
+    if (D == Dc) { // the other common padded dimensions (k_scan2.hip): 256, 384, 512, 1024, 1536
+        bool handled = false;
+        const hipError_t e = launch_scan_more_dims(P, nq, lds, device, s, ev0, ev1, &handled);
+        if (handled) return e;
+    }
+    return launch_scan_d<0>(P, nq, lds, device, s, ev0, ev1); // any other dimension: runtime-dimension kernel
 }
+#else
+// second translation unit of the same kernel template (compiled in parallel with the first): the compile-time dimension
+// buys the rolling two-granule code window and immediate LUT offsets — the reference runs every multiple of 64 through one
+// SIMD body (src/simd.rs:972-1014), so the common embedding sizes get the same treatment as 128 / 768 / 960
+hipError_t launch_scan_more_dims(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                                 bool* handled) {
+    *handled = true;
+    switch (P.D) {
+        case 256: return launch_scan_d<256>(P, nq, lds, device, s, ev0, ev1);
+        case 384: return launch_scan_d<384>(P, nq, lds, device, s, ev0, ev1);
+        case 512: return launch_scan_d<512>(P, nq, lds, device, s, ev0, ev1);
+        case 1024: return launch_scan_d<1024>(P, nq, lds, device, s, ev0, ev1);
+        case 1536: return launch_scan_d<1536>(P, nq, lds, device, s, ev0, ev1);
+        default: *handled = false; return hipSuccess;
+    }
+}
+#endif
 
 } // namespace rbq

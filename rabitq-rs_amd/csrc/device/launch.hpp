@@ -81,7 +81,10 @@ struct SelectParams {
     int lazy;                     // 0: every probed list is scored and streamed (round-2 behaviour)
     int exact_members;            // diagnostics: dead_skipped and the probed-vector count must be exact
 };
-hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s);
+// key_window: null, or [nq][select_exact_np2(nprobe)] u64 in global memory (nprobe > kNprobeMax: the exact path with its key
+// window outside the LDS — slow, but every nprobe up to n_lists is served, as the reference does, src/ivf.rs:1791)
+uint32_t select_exact_np2(uint32_t nprobe);
+hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s, uint64_t* key_window);
 hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s);
 
 struct ProbesGivenParams {

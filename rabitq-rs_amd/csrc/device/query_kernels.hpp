@@ -575,10 +575,12 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
                                                      unsigned long long* __restrict__ nvec_probed,
                                                      unsigned long long* __restrict__ prof_total,
                                                      const QueryConsts* __restrict__ consts,
-                                                     const BlockSummary* __restrict__ bsum) {
+                                                     const BlockSummary* __restrict__ bsum, uint64_t* gsel) {
+    // gsel != null: the key window [nq][np2] lives in global memory (nprobe beyond what the LDS of one compute unit holds:
+    // the reference only clamps nprobe to the number of lists, src/ivf.rs:1791 — slow here, but served)
     extern __shared__ __align__(16) unsigned char smraw[];
-    uint64_t* sel = reinterpret_cast<uint64_t*>(smraw);
-    float* qrot = reinterpret_cast<float*>(smraw + (size_t)np2 * 8);
+    uint64_t* sel = gsel ? gsel + (size_t)blockIdx.x * np2 : reinterpret_cast<uint64_t*>(smraw);
+    float* qrot = reinterpret_cast<float*>(smraw + (gsel ? (size_t)0 : (size_t)np2 * 8));
     uint32_t* part = reinterpret_cast<uint32_t*>(qrot + D);
     __shared__ uint32_t hist[256];
     __shared__ uint64_t s_prefix, s_mask;
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
     __syncthreads();
     const uint64_t kstar = s_prefix;
     for (uint32_t i = tid; i < np2; i += kThreads) sel[i] = ~0ull;
+    if (gsel) __threadfence_block();
     __syncthreads();
     for (uint32_t i = tid; i < nlist; i += kThreads) {
         uint64_t key = make_key(sc[i], i, metric);
@@ -629,6 +632,7 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
             if (pos < np2) sel[pos] = key;
         }
     }
+    if (gsel) __threadfence_block(); // (global window: the workgroup's own writes are read back by other lanes)
     __syncthreads();
     // bitonic sort ascending
     for (uint32_t k = 2; k <= np2; k <<= 1)
@@ -641,6 +645,7 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
                     if ((a > b) == up) { sel[i] = b; sel[ixj] = a; }
                 }
             }
+            if (gsel) __threadfence_block();
             __syncthreads();
         }
 

@@ -105,11 +105,12 @@ struct PinBuf { // page-locked host staging
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     void release() {
-        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped})
+        for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
+                          &heap_ws, &key_window})
             b->release();
         h_in.release(); h_out.release();
         if (done) (void)hipEventDestroy(done);
@@ -972,6 +973,12 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.mstg = mstg ? 1u : 0u;
     P.prof = ix->profiling ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
+    P.heap_ws = nullptr;
+    if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
+        int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);
+        if (rc) return rc;
+        P.heap_ws = (uint32_t*)w->heap_ws.p;
+    }
     HIP_TRY(launch_scan(P, (uint32_t)nq, ix->device, stream, ps.start(), ps.stop()));
     return RBQ_OK;
 }
@@ -984,9 +991,11 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     const uint32_t nlist = (uint32_t)ix->n_lists;
     uint32_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
     if (nprobe > nlist) nprobe = nlist;
-    if (nprobe > kNprobeMax) return fail(RBQ_INVALID_CONFIG, "nprobe > 8192 is not supported by the GPU probe selector (its shortlist lives in the LDS of one compute unit)");
-    if (top_k > kTopKMax || scan_lds_bytes(Dc, D, ix->ex_bits, top_k) > kLdsPerWorkgroupMax)
-        return fail(RBQ_INVALID_CONFIG, "top_k > 16384 is not supported by the GPU top-k stage (the exact heap lives in the LDS of one compute unit)");
+    // nprobe > kNprobeMax: the exact all-pairs ranking with its key window in global memory; top_k > kTopKMax: the heap in
+    // global memory — both slow, both served (the reference clamps nprobe to n_lists and accepts any top_k)
+    const bool big_nprobe = nprobe > kNprobeMax;
+    if (top_k > kTopKHardMax || (uint64_t)nq * ((uint64_t)top_k + 1) * 8 > (8ull << 30))
+        return fail(RBQ_INVALID_CONFIG, "top_k too large for one call (top_k <= 2^20 and nq * top_k * 8 bytes of heap workspace <= 8 GiB)");
     if (ix->rerank && top_k > 1024) return fail(RBQ_INVALID_CONFIG, "rerank supports top_k <= 1024");
     const uint64_t wl_stride = std::max<uint64_t>(ix->nblk_desc_prefix[nprobe], 1);
 
@@ -1035,15 +1044,20 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     // exists) and not when every probed block is to be streamed
     sp.lazy = (ix->lazy_select && !d_filter && !ix->no_block_bound) ? 1 : 0;
     sp.exact_members = d_diag ? 1 : 0;
-    if (ix->exact_rank) {
+    if (ix->exact_rank || big_nprobe) {
+        uint64_t* kw = nullptr;
+        if (big_nprobe) {
+            if ((rc = w->key_window.ensure((size_t)nq * select_exact_np2(nprobe) * 8))) return rc;
+            kw = (uint64_t*)w->key_window.p;
+        }
         { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_exact(rp, stream)); }
-        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, ix->device, stream)); }
+        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, ix->device, stream, kw)); }
     } else {
         { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); }           // approximate scores: one MFMA GEMM
         { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
     if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
-                         /*mstg=*/false, ix->exact_rank ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
+                         /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
         return rc;
     if (ix->rerank) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
         HIP_TRY(launch_rerank(d_queries, (uint32_t)nq, ix->dim, (const float*)ix->raw.p, ix->n_raw, ix->metric, top_k, d_ids, d_scores,
@@ -1424,8 +1438,8 @@ int rbq_posting_scan_batch(const rbq_index* ch, const float* queries, uint64_t n
     if (nq == 0) return RBQ_OK;
     if (!queries || !list_ids || !list_counts || !out_ids || !out_scores || !out_counts) return fail(RBQ_INVALID_CONFIG, "null buffer");
     if (top_k == 0) { std::memset(out_counts, 0, nq * 4); return RBQ_OK; }
-    if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, ix->ex_bits, top_k) > kLdsPerWorkgroupMax)
-        return fail(RBQ_INVALID_CONFIG, "top_k > 16384 is not supported by the GPU top-k stage (the exact heap lives in the LDS of one compute unit)");
+    if (top_k > kTopKHardMax || (uint64_t)std::min<uint64_t>(nq, 16384) * ((uint64_t)top_k + 1) * 8 > (8ull << 30))
+        return fail(RBQ_INVALID_CONFIG, "top_k too large for one call (top_k <= 2^20)");
     if (max_lists == 0) {
         std::memset(out_counts, 0, nq * 4);
         for (uint64_t i = 0; i < nq * top_k; ++i) { out_ids[i] = ~0ull; out_scores[i] = NAN; }

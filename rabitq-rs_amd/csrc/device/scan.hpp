@@ -683,9 +683,16 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
     uint8_t* s_lut = smraw;
     float* s_q = reinterpret_cast<float*>(smraw + (size_t)Dc * 4);
+    // the exact heap of top_k + 1 entries: in LDS, or (top_k beyond the LDS: the reference accepts any top_k, src/ivf.rs:2116-2126)
+    // in this query's slice of a global workspace — one lane works on it either way
+    const uint32_t hk = P.heap_ws ? 0u : P.top_k + 1u;
     float* heap_d = s_q + ex_qlen(D, DT ? (uint32_t)EX : P.ex_bits);
-    uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
-    uint32_t* q_slot = heap_s + (P.top_k + 1);                      // [2][kTileCand]
+    uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + hk);
+    uint32_t* q_slot = heap_s + hk;                      // [2][kTileCand]
+    if (P.heap_ws) {
+        heap_d = reinterpret_cast<float*>(P.heap_ws + (size_t)blockIdx.x * 2 * ((size_t)P.top_k + 1));
+        heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
+    }
     float* q_lb = reinterpret_cast<float*>(q_slot + 2 * kTileCand);
     float* q_ip = q_lb + 2 * kTileCand;
     float* q_gadd = q_ip + 2 * kTileCand;
@@ -1192,6 +1199,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                         }
                         lh.len = (uint32_t)__builtin_amdgcn_readfirstlane((int)lh.len);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (P.heap_ws) __threadfence_block(); // (global heap: lane 0's stores before the wave reads the root again)
                     }
                 }
             };
@@ -1305,6 +1313,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             lh.into_sorted();
             s_len = lh.len;
         }
+        if (P.heap_ws) __threadfence_block(); // (global heap: visible to the other waves behind the barrier below)
         }
         if (lane != 0) { n_skip = 0; n_ext = 0; n_est = 0; } // uniform counters: report them once
     }

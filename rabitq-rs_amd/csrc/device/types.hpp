@@ -98,6 +98,7 @@ struct ScanParams {
     uint32_t mstg;           // MSTG posting-list semantics (src/mstg/index.rs:216-330): distance = binary estimate,
                              // non-finite dropped, L2 clamped to >= 0, no error-bound term
     unsigned long long* prof; // null, or the traffic counters of kProf* below (one atomicAdd per workgroup at exit)
+    uint32_t* heap_ws;            // null, or [nq][2 * (top_k + 1)] words: the exact heap in global memory (top_k beyond the LDS)
     const uint32_t* dead_skipped; // [nq] vectors of probed lists that the probe selection proved skipped as a whole (they
                                   // never enter the stream; diagnostics add them to skipped_by_lower_bound), or null
 };
@@ -120,8 +121,11 @@ constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
 constexpr int kQueueCap = kTileBlocks - 1 + kWindow <= 512 ? 512 : 1024; // live-block FIFO (>= kTileBlocks - 1 + kWindow)
 static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
-constexpr uint32_t kNprobeMax = 8192;             // largest nprobe after the clamp to n_lists (k_select_mfma: 2 x nprobe u64 keys in LDS)
-constexpr uint32_t kTopKMax = 16384;              // largest top_k at all: above kTopKRegMax the exact heap is an LDS array of top_k + 1 entries
+constexpr uint32_t kNprobeMax = 8192;             // largest nprobe of the MFMA-shortlist selector (2 x nprobe u64 keys in LDS); above it the
+                                                  // exact all-pairs ranking with its key window in global memory serves the call
+constexpr uint32_t kTopKMax = 16384;              // largest top_k whose exact heap (top_k + 1 entries) fits the LDS; above it the heap of
+                                                  // each query lives in global memory (ScanParams::heap_ws)
+constexpr uint32_t kTopKHardMax = 1u << 20;       // largest top_k at all
 constexpr size_t kLdsPerWorkgroupMax = 160 * 1024; // LDS of one compute unit (gfx950)
 
 // Device layout of the ex codes ("lane-major"): per vector 16 lanes x W4 units of 16 B, stored [unit][lane][16 B].
@@ -142,8 +146,9 @@ __host__ __device__ inline uint32_t ex_qlen(uint32_t D, uint32_t ex_bits) {
 //   lut[4Dc] u8 | qrot[D] f32 | heap_d[k+1] f32 | heap_s[k+1] u32 | q_slot,q_lb,q_ip,q_gadd,q_d [2][kTileCand] |
 //   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
 //   T, len, nskip, nbatch | batch[kScanThreads/16] u32
-__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k) {
-    return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (size_t)(top_k + 1) * 8 + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
+// (heap_in_lds = false: the heap lives in global memory, ScanParams::heap_ws)
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k, bool heap_in_lds = true) {
+    return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (heap_in_lds ? (size_t)(top_k + 1) * 8 : (size_t)0) + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
            2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 8;
 }
 

@@ -500,7 +500,8 @@ def test_gpu_matches_committed_vectors():
 @pytest.mark.parametrize("nprobe", [4096, 5000, 8192])
 def test_nprobe_up_to_the_limit(nprobe):
     """Thousands of probes per query (the reference clamps nprobe to n_lists and nothing else): the shortlist window of
-    k_select_mfma grows to 16 384 keys; 8193 is RBQ_INVALID_CONFIG."""
+    k_select_mfma grows to 16 384 keys; above 8192 the exact all-pairs ranking with its key window in global memory takes
+    over (nprobe = 8193 and nprobe = n_lists = 9000)."""
     import torch
     nlist, dim = 9000, 64
     n = 3 * nlist
@@ -514,9 +515,8 @@ def test_nprobe_up_to_the_limit(nprobe):
     q = make_dataset(6, dim, 64, 68)
     _compare(built, idx, q, 10, nprobe)
     if nprobe == 8192:
-        with pytest.raises(rq.RabitqError) as e:
-            idx.batch_search_raw(q, rq.SearchParams(10, 8193))
-        assert e.value.kind == "InvalidConfig" and "8192" in e.value.detail
+        _compare(built, idx, q[:3], 10, 8193)
+        _compare(built, idx, q[:3], 10, 20000)  # clamped to n_lists = 9000 (src/ivf.rs:1791)
     idx.close()
 
 
@@ -553,16 +553,20 @@ def test_large_top_k(top_k):
 
 
 def test_top_k_6000_with_evictions_and_limit():
-    """A heap of 6000 entries in LDS that fills up and evicts (every list probed: 20 000 candidates per query), and the
-    documented limit: top_k 16385 is RBQ_INVALID_CONFIG."""
+    """A heap of 6000 entries in LDS that fills up and evicts (every list probed: 20 000 candidates per query); beyond the LDS
+    (top_k 16385, 19999: heap in global memory, evictions; 20000 and 30000: every candidate returned) the call is served as the
+    reference serves it; only top_k > 2^20 is RBQ_INVALID_CONFIG."""
     data, built = build_index(n=20000, dim=64, nlist=16, total_bits=3, seed=73)
     idx = rq.IvfRabitqIndex.from_built(built)
     q = make_dataset(6, 64, 6, 74)
     ids, sc, cnt = _compare(built, idx, q, 6000, 16)
     assert (cnt == 6000).all()
+    for top_k in (16385, 19999, 20000, 30000):
+        ids, sc, cnt = _compare(built, idx, q[:3], top_k, 16)
+        assert (cnt == min(top_k, 20000)).all()
     with pytest.raises(rq.RabitqError) as e:
-        idx.batch_search_raw(q, rq.SearchParams(16385, 4))
-    assert e.value.kind == "InvalidConfig" and "16384" in e.value.detail
+        idx.batch_search_raw(q, rq.SearchParams((1 << 20) + 1, 4))
+    assert e.value.kind == "InvalidConfig" and "2^20" in e.value.detail
     idx.close()
 
 

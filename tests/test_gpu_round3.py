@@ -166,3 +166,21 @@ def test_bench_in_library_two_replicas():
     assert d["n_gpus"] == 2 and d["replicas"] == 2 and d["value"] > 0
     assert d["ids_identical_to_one_replica_device_entry"] and d["recall_at_10"] > 0.9
     assert set(d["latency"]) >= {"1", "8", "64", "256"} and d["latency"]["1"]["p50_us"] > 0
+
+
+# ---- compile-time scan instantiations for the common padded dimensions ---------------------------------------------------
+@pytest.mark.parametrize("dim,bits,metric", [(256, 7, 0), (384, 3, 1), (512, 7, 0), (1024, 7, 0), (1024, 1, 1), (1536, 3, 0), (500, 7, 0)])
+def test_scan_dimension_instantiations(dim, bits, metric):
+    """k_scan<D, ex, TR> for D in {256, 384, 512, 1024, 1536} (k_scan2.hip: rolling code window, immediate LUT offsets), and
+    a dimension that has no instantiation (500 -> padded 512 with dim < padded_dim; 320, 200 elsewhere take the
+    runtime-dimension kernel): the reference serves every multiple of 64 with one body (src/simd.rs:972-1014)."""
+    data, built = build_index(n=5000, dim=dim, nlist=32, total_bits=bits, metric=metric, normalize=(metric == 1), seed=600 + dim + bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(601)
+    q = data[rng.choice(5000, 24, replace=False)] + 0.05 * rng.standard_normal((24, dim)).astype(np.float32)
+    if metric == 1:
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    for top_k, nprobe in ((10, 8), (100, 12), (200, 32)):
+        _compare(built, idx, q, top_k, nprobe)
+    idx.close()
