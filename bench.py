@@ -834,13 +834,13 @@ def main():
                         "approach the device-resident rate.  `value` is the device-resident rate; these are the rates a host-side "
                         "caller sees.")
 
-    latency = latency_leg() if (rank == 0 and not a.no_latency and not a.ab) else None
+    latency = latency_leg() if (extras and not a.no_latency) else None
 
     # Self-check for indexes no CPU oracle run can cover (device-built: cfg5 at 100 M vectors): the first 256 queries again
     # with every shortcut switched off — canonical all-pairs ranking instead of the MFMA shortlist, BinaryHeap emulation from
     # the first candidate, no block-level bound — must give the same bits.
     self_check = None
-    if rank == 0 and not a.ab:
+    if extras:
         nsc = min(256, a.batch)
         qs_ = q_all[0][:nsc].contiguous()
         def run_sc():

@@ -208,8 +208,10 @@ __device__ __forceinline__ void fht_exchange(float (&v)[EPL], uint32_t lane) {
     }
 }
 
+// `flip` != null: the flip-sign bits of the elements of `part` (LSB-first, bit i = element i), applied as the elements are
+// loaded (flip_sign of the round fused into the transform's own read: no separate pass over the vector)
 template <int EPL>
-__device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) {
+__device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac, const uint8_t* flip = nullptr) {
     float v[EPL];
     if (EPL >= 4) {
 #pragma unroll
@@ -220,6 +222,13 @@ __device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) 
     } else {
 #pragma unroll
         for (int k = 0; k < EPL; ++k) v[k] = part[lane * EPL + k];
+    }
+    if (flip) {
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const uint32_t i = lane * EPL + k;
+            if ((flip[i >> 3] >> (i & 7u)) & 1u) v[k] = -v[k];
+        }
     }
 #pragma unroll
     for (int h = 1; h < EPL; h <<= 1)
@@ -246,33 +255,56 @@ __device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac) 
     }
 }
 
-// FhtKacRotator::rotate_into by one wave; `flips` = the 4*D/8 flip-sign bytes (LDS copy).  Same operations as
-// rotate_into_lds<64>, with fht_wave in place of the LDS butterflies.
+// FhtKacRotator::rotate_into by one wave; `flips` = the 4*D/8 flip-sign bytes (LDS copy).  Same operations on the same
+// values as rotate_into_lds<64> (src/rotation.rs:350-401), with fht_wave in place of the LDS butterflies and the sign flips
+// and the final scale FUSED into the passes next to them (a negation commutes with nothing else here: it is applied to
+// the very value the separate pass would have negated): round 0's flips by the initial load, round r+1's flips by the
+// Kac step of round r as it writes (or, for power-of-two dimensions, by the transform as it reads), the closing * 0.25
+// by the last Kac step.  Per round the vector makes 4 passes through LDS as 16-byte accesses instead of 6 as scalars:
+// the rotation was 17 of the 27 us of a single query's preparation.
+// The initial load (with round 0's flips unless the dimension is a power of two) — a separate step so that the caller can issue
+// it BEFORE the barrier behind the copy of the flip bits into LDS: `flips0` may be the global table.
+__device__ __forceinline__ void fhtkac_initial_load(float* x, const float* __restrict__ qin, uint32_t dim, uint32_t D, uint32_t trunc,
+                                                    const uint8_t* __restrict__ flips0, uint32_t lane) {
+    for (uint32_t i = lane; i < D; i += 64) {
+        const float v = i < dim ? qin[i] : 0.0f;
+        x[i] = (trunc != D && ((flips0[i >> 3] >> (i & 7u)) & 1u)) ? -v : v;
+    }
+}
 template <int EPL>
-__device__ __forceinline__ void rotate_fhtkac_wave(float* x, const float* __restrict__ qin, uint32_t dim, uint32_t D,
-                                                   const uint8_t* flips, float fac, uint32_t lane) {
+__device__ __forceinline__ void rotate_fhtkac_wave(float* x, uint32_t D, const uint8_t* flips, float fac, uint32_t lane) {
     constexpr uint32_t trunc = 64u * EPL;
-    for (uint32_t i = lane; i < D; i += 64) x[i] = i < dim ? qin[i] : 0.0f;
-    group_sync<64>();
     const uint32_t fo = D / 8, start = D - trunc, half = D / 2;
-    for (int r = 0; r < 4; ++r) {
-        const uint8_t* f = flips + r * fo;
-        for (uint32_t i = lane; i < D; i += 64)
-            if ((f[i >> 3] >> (i & 7)) & 1) x[i] = -x[i];
-        group_sync<64>();
-        fht_wave<EPL>((trunc != D && (r & 1)) ? x + start : x, lane, fac);
-        group_sync<64>();
-        if (trunc != D) {
-            for (uint32_t i = lane; i < half; i += 64) {
-                const float a = x[i], b = x[i + half];
-                x[i] = a + b;
-                x[i + half] = a - b;
-            }
+    group_sync<64>(); // (fhtkac_initial_load)
+    if (trunc == D) { // 4 x (flip, transform of everything, scale)
+        for (int r = 0; r < 4; ++r) {
+            fht_wave<EPL>(x, lane, fac, flips + r * fo);
             group_sync<64>();
         }
+        return;
     }
-    if (trunc != D) {
-        for (uint32_t i = lane; i < D; i += 64) x[i] = x[i] * 0.25f;
+    for (int r = 0; r < 4; ++r) {
+        fht_wave<EPL>((r & 1) ? x + start : x, lane, fac);
+        group_sync<64>();
+        // Kac step, four pairs (i, i + half) per lane and step; then the next round's flips, or the closing scale
+        const uint8_t* fn = flips + (r + 1) * fo;
+        for (uint32_t i = 4 * lane; i < half; i += 256) { // half % 32 == 0
+            const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + i + half);
+            float s[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}, d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+            if (r < 3) {
+                const uint32_t fs = (uint32_t)fn[i >> 3] >> (i & 7u), fd = (uint32_t)fn[(i + half) >> 3] >> ((i + half) & 7u); // (i, half: multiples of 4)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((fs >> k) & 1u) s[k] = -s[k];
+                    if ((fd >> k) & 1u) d[k] = -d[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[k] = s[k] * 0.25f; d[k] = d[k] * 0.25f; }
+            }
+            *reinterpret_cast<float4*>(x + i) = make_float4(s[0], s[1], s[2], s[3]);
+            *reinterpret_cast<float4*>(x + i + half) = make_float4(d[0], d[1], d[2], d[3]);
+        }
         group_sync<64>();
     }
 }
@@ -313,25 +345,29 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t q = blockIdx.x * (kThreads / 64) + wave;
     uint8_t* flips = reinterpret_cast<uint8_t*>(sm + (size_t)2 * (kThreads / 64) * D); // 4*D/8 bytes (FHT-Kac)
-    if (rotator == 1) {
-        for (uint32_t i = threadIdx.x; i < D / 2; i += kThreads) flips[i] = rot_blob[i];
-        __syncthreads(); // the only workgroup barrier: before any wave can leave
-    }
-    if (q >= nq) return; // whole wave
 #ifdef RBQ_PREP_STAMPS
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
 #endif
     float* x = sm + (size_t)wave * 2 * D;
     float* x2 = x + D; // squares, for the |q|^2 chain
     const float* qin = queries + (size_t)q * dim;
+    const bool wave_fht = rotator == 1 && trunc >= 64 && trunc <= 2048; // (else the generic LDS butterflies)
+    if (rotator == 1) {
+        for (uint32_t i = threadIdx.x; i < D / 2; i += kThreads) flips[i] = rot_blob[i];
+        // the query is requested together with the flip table (round 0's flips straight from the global table): one
+        // round trip in front of the barrier instead of two around it
+        if (q < nq && wave_fht) fhtkac_initial_load(x, qin, dim, D, trunc, rot_blob, lane);
+        __syncthreads(); // the only workgroup barrier: before any wave can leave
+    }
+    if (q >= nq) return; // whole wave
     if (rotator == 1) {
         switch (trunc) {
-            case 64: rotate_fhtkac_wave<1>(x, qin, dim, D, flips, fac, lane); break;
-            case 128: rotate_fhtkac_wave<2>(x, qin, dim, D, flips, fac, lane); break;
-            case 256: rotate_fhtkac_wave<4>(x, qin, dim, D, flips, fac, lane); break;
-            case 512: rotate_fhtkac_wave<8>(x, qin, dim, D, flips, fac, lane); break;
-            case 1024: rotate_fhtkac_wave<16>(x, qin, dim, D, flips, fac, lane); break;
-            case 2048: rotate_fhtkac_wave<32>(x, qin, dim, D, flips, fac, lane); break;
+            case 64: rotate_fhtkac_wave<1>(x, D, flips, fac, lane); break;
+            case 128: rotate_fhtkac_wave<2>(x, D, flips, fac, lane); break;
+            case 256: rotate_fhtkac_wave<4>(x, D, flips, fac, lane); break;
+            case 512: rotate_fhtkac_wave<8>(x, D, flips, fac, lane); break;
+            case 1024: rotate_fhtkac_wave<16>(x, D, flips, fac, lane); break;
+            case 2048: rotate_fhtkac_wave<32>(x, D, flips, fac, lane); break;
             // dim < 64 (transform shorter than a wavefront) or >= 4096: the generic LDS butterflies
             default: rotate_into_lds<64>(x, nullptr, qin, dim, D, rotator, flips, trunc, fac, lane); break;
         }

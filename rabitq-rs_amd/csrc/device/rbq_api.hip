@@ -190,39 +190,51 @@ struct Replica {
 } // namespace
 
 namespace {
-// One persistent host thread per replica beyond the first (rbq_search_batch on N replicas): the shard of replica r is
-// enqueued and awaited by worker r while the caller's own thread serves replica 0.  Started on the first multi-replica
-// call, joined when the index is destroyed — no thread is created per call (8 replicas: seven thread start-ups of 30-50 us
-// each per call were as long as a 1024-query shard itself).
+// Persistent host threads per replica beyond the first (rbq_search_batch on N replicas): the shard of replica r is
+// enqueued and awaited by a worker of replica r while the caller's own thread serves replica 0.  Started on the first
+// multi-replica call, joined when the index is destroyed — no thread is created per call (8 replicas: seven thread start-ups
+// of 30-50 us each per call were as long as a 1024-query shard itself).  Two threads per replica, so that the shards of two
+// concurrent callers overlap on it; a worker that has just finished a job polls for the next one for ~100 us before it
+// blocks (a caller that issues calls back to back does not pay a wake-up per call).
 struct ReplicaWorker {
-    std::thread th;
+    static constexpr int kThreadsPerReplica = 2;
+    std::thread th[kThreadsPerReplica];
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::function<void()>> jobs;
+    std::atomic<uint32_t> pending{0};
     bool stop = false;
-    void start() {
-        th = std::thread([this] {
-            for (;;) {
-                std::function<void()> job;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [this] { return stop || !jobs.empty(); });
-                    if (jobs.empty()) return; // stop requested and nothing left
-                    job = std::move(jobs.front());
-                    jobs.pop_front();
-                }
-                job();
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return; // stop requested and nothing left
+                job = std::move(jobs.front());
+                jobs.pop_front();
             }
-        });
+            job();
+            pending.fetch_sub(1, std::memory_order_release);
+            const auto t0 = std::chrono::steady_clock::now(); // short poll before blocking again
+            while (pending.load(std::memory_order_acquire) == 0 &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(100)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
     }
+    void start() { for (auto& t : th) t = std::thread([this] { run(); }); }
     void post(std::function<void()> job) {
+        pending.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(job)); }
         cv.notify_one();
     }
     void shutdown() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_one();
-        if (th.joinable()) th.join();
+        cv.notify_all();
+        for (auto& t : th) if (t.joinable()) t.join();
     }
 };
 } // namespace
@@ -1416,8 +1428,13 @@ int rbq_search_batch(const rbq_index* ch, const float* queries, uint64_t nq, uin
         });
     shard(0);
     {
+        // the other shards finish about when this one does: poll briefly before blocking on the latch
+        const auto t0 = std::chrono::steady_clock::now();
         std::unique_lock<std::mutex> lk(latch.mu);
-        latch.cv.wait(lk, [&] { return latch.left == 0; });
+        while (latch.left != 0) {
+            if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
+            else latch.cv.wait(lk, [&] { return latch.left == 0; });
+        }
     }
     for (size_t r = 0; r < R; ++r) if (rcs[r]) return fail(rcs[r], details[r]);
     return RBQ_OK;

@@ -291,6 +291,42 @@ __device__ __forceinline__ void ex_dot_pair1(const uint4& u0, const uint4& u1, c
         }
     }
 }
+// The same for vectors whose codes span NU units per lane (NU = 2, 3: D = 768 / 960 at 6 bits), on PACKED f32 FMAs: the two
+// survivors' chains are the two halves of one v_pk_fma_f32 per code (each half is the reference's own fused
+// multiply-add, in its own order), the query value is read from LDS once for both.  Per code: 2 extractions, 2 converts,
+// 1 LDS read, 1 packed FMA instead of 2 x (extract, convert, LDS read, FMA).  Used for top_k >= 64, where most refined
+// candidates enter the top-k and a refine round of twice the size is not wasted work.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int EX, int NU>
+__device__ __forceinline__ void ex_dot_pair_units(const uint4* __restrict__ p0, const uint4* __restrict__ p1, const float* sq, uint32_t gl,
+                                                  float& s0, float& s1) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    f32x2 acc = {0.0f, 0.0f};
+    uint4 c0v = p0[0], c1v = p1[0]; // unit j of both vectors in registers, unit j + 1 in flight (all NU units of both: spills)
+#pragma unroll 1
+    for (int j = 0; j < NU; ++j) { // (a real loop: fully unrolled, hipcc keeps all 3 x 21 query values of a vector pair alive)
+        const int jn = j + 1 < NU ? j + 1 : j;
+        const uint4 n0v = p0[jn * 16], n1v = p1[jn * 16];
+        const uint32_t w0[5] = {c0v.x, c0v.y, c0v.z, c0v.w, 0u}, w1[5] = {c1v.x, c1v.y, c1v.z, c1v.w, 0u};
+        const float* qj = sq + j * CPU * 16 + gl;
+#pragma unroll
+        for (int k = 0; k < CPU; ++k) {
+            const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+            uint32_t c0, c1;
+            if (sh + EX <= 32) { c0 = (w0[idx] >> sh) & mask; c1 = (w1[idx] >> sh) & mask; }
+            else {
+                c0 = ((w0[idx] >> sh) | (w0[idx + 1] << (32 - sh))) & mask;
+                c1 = ((w1[idx] >> sh) | (w1[idx + 1] << (32 - sh))) & mask;
+            }
+            const float qv = qj[16 * k]; // (zero beyond D: the padded code slots are zero as well, 0 * 0 + s == s)
+            const f32x2 cf = {(float)c0, (float)c1}, qq = {qv, qv};
+            acc = __builtin_elementwise_fma(cf, qq, acc);
+        }
+        c0v = n0v; c1v = n1v;
+    }
+    s0 = acc.x; s1 = acc.y;
+}
 __device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_add_ps halving tree
     sacc = sacc + __shfl_xor(sacc, 8, 16);
     sacc = sacc + __shfl_xor(sacc, 4, 16);
@@ -673,6 +709,9 @@ struct SortedRun {
 #ifndef RBQ_WIN_GROW
 #define RBQ_WIN_GROW 4
 #endif
+#ifndef RBQ_WIN0
+#define RBQ_WIN0 kTileBlocks // stream entries examined by the first fill step
+#endif
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
 // TR: registers per lane of the replay wave's top-k (1: top_k <= 63; 2: <= 128; 4: <= 256 — with more than one,
 // four waves per SIMD instead of five).
@@ -782,7 +821,13 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     // heavy tiles: survivors a 16-lane group refines per round when a vector's codes span several units (one after the
     // other; twice the batch = half the rounds of barrier + collect + replay, at the price of a larger superset)
     constexpr int kHeavyPer = RBQ_HEAVY_PER;
-    constexpr bool kDual = DT != 0 && EX != 0 && ex_w4((uint32_t)(DT ? DT : 16), (uint32_t)(EX ? EX : 2)) == 1u;
+    constexpr uint32_t kNU = ex_w4((uint32_t)(DT ? DT : 16), (uint32_t)(EX ? EX : 2)); // code units per lane and vector
+    constexpr bool kDual1 = DT != 0 && EX != 0 && kNU == 1u;
+#ifndef RBQ_PAIR_UNITS
+#define RBQ_PAIR_UNITS 1
+#endif
+    constexpr bool kDualN = RBQ_PAIR_UNITS && DT != 0 && EX != 0 && TR > 1 && kNU >= 2u && kNU <= 3u; // packed pair refine (top_k >= 64)
+    constexpr bool kDual = kDual1 || kDualN;
     auto refine_pair = [&](uint32_t buf, uint32_t nb, uint32_t g, uint32_t ng) {
         const uint32_t gl = tid & 15u;
         if (g >= nb) return;
@@ -790,13 +835,17 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         const uint32_t e0 = buf * kTileCand + s_batch[g];
         const uint32_t e1 = buf * kTileCand + s_batch[has1 ? g + ng : g];
         const uint32_t sl0 = q_slot[e0], sl1 = q_slot[e1];
-        const uint4 u0 = *(reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl0 * exb) + gl);
-        const uint4 u1 = *(reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl1 * exb) + gl);
+        const uint4* p0 = reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl0 * exb) + gl;
+        const uint4* p1 = reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl1 * exb) + gl;
         float fa0 = P.f_add_ex[sl0], fr0 = P.f_rescale_ex[sl0], fa1 = P.f_add_ex[sl1], fr1 = P.f_rescale_ex[sl1];
         asm volatile("" : "+v"(fa0), "+v"(fr0), "+v"(fa1), "+v"(fr1)); // issue the loads here
         float sa, sb;
-        if (EX == 6) ex_dot_pair1<6>(u0, u1, s_q, gl, D / 16, sa, sb);
-        else ex_dot_pair1<(EX ? EX : 2)>(u0, u1, s_q, gl, D / 16, sa, sb);
+        if (kDualN) ex_dot_pair_units<(EX ? EX : 2), (kDualN ? (int)kNU : 1)>(p0, p1, s_q, gl, sa, sb);
+        else {
+            const uint4 u0 = p0[0], u1 = p1[0];
+            if (EX == 6) ex_dot_pair1<6>(u0, u1, s_q, gl, D / 16, sa, sb);
+            else ex_dot_pair1<(EX ? EX : 2)>(u0, u1, s_q, gl, D / 16, sa, sb);
+        }
         sa = group16_reduce(sa);
         sb = group16_reduce(sb);
         if (gl == 0) {
@@ -861,7 +910,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     // block bound passes everything, and whatever is queued then is paid for at tile time (factor rows, a
     // barrier, usually no survivor).  Once the nearest lists have set a threshold the windows grow
     // (x RBQ_WIN_GROW per step, up to kFillK entries per scanner lane).
-    uint32_t win = (uint32_t)kTileBlocks;
+    uint32_t win = (uint32_t)(RBQ_WIN0);
     // replay-wave state
     const bool reg_heap = top_k < 64u * TR;                     // exact BinaryHeap emulation in registers (else in LDS)
     // RankRun from top_k = 64; below, the one-register sorted run (RankRun there costs the hot kernel 20 bytes of scratch at
@@ -1278,7 +1327,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         if (P.heap_restarts) atomicAdd(P.heap_restarts, 1u);
     }
     fast = false;
-    pos = 0; qhead = 0; qcount = 0; tile = 0; win = (uint32_t)kTileBlocks;
+    pos = 0; qhead = 0; qcount = 0; tile = 0; win = (uint32_t)(RBQ_WIN0);
     ++p_pass;
     n_skip = 0; n_ext = 0; n_est = 0;
     rh.len = 0;

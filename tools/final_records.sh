@@ -5,13 +5,17 @@ out=gpurun_out/final; rm -rf $out; mkdir -p $out
 run() { name=$1; shift; python bench.py "$@" 2> $out/$name.err | grep '^{' | tail -n 1 > $out/$name.json; python - $out/$name.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); p = d.get('pruned') or {}
-print(sys.argv[1], round(d['value']), 'q/s', round(d['ms_per_step'], 4), 'ms/step recall', d.get('recall_at_10', d.get('recall')), 'roofline', round(d['roofline']['frac'], 3), 'skip', round(p.get('block_skip_frac', 0), 4))
+rec = [v for k, v in d.items() if k.startswith('recall_at')]
+print(sys.argv[1], round(d['value']), 'q/s', round(d['ms_per_step'], 4), 'ms/step recall', rec, 'roofline', round(d['roofline']['frac'], 3) if d.get('roofline') else None,
+      'skip', round(p.get('block_skip_frac', 0), 4), 'stage', d.get('stage_ms'))
 PY
 }
-run bench_end_gist1m_b1024_steps20 --steps 20
-run bench_end_gist1m_b1024_steps200 --steps 200 --no-cpu --no-extras
-run bench_end_top100 --top-k 100 --no-cpu --no-extras
-run bench_end_top100_steps200 --top-k 100 --steps 200 --no-cpu --no-extras
-run bench_end_b4096 --batch 4096 --nbatches 8 --no-cpu --no-extras
-run bench_end_sift --dim 128 --nlist 1024 --nprobe 64 --no-cpu --no-extras
-run bench_end_ip3 --bits 3 --metric 1 --nprobe 256 --no-cpu --no-extras
+run bench_headline_steps20 --steps 20 --warmup 5
+run bench_headline_steps200 --steps 200 --no-cpu --ab
+run bench_cfg2 --config cfg2 --steps 100 --no-cpu --ab
+run bench_cfg3_b4096 --config cfg3_b4096 --steps 50 --no-cpu --ab
+run bench_cfg4 --config cfg4 --steps 100 --no-cpu --ab
+run bench_top100 --config top100 --steps 100 --no-cpu --ab
+run bench_top100_steps200 --config top100 --steps 200 --no-cpu --ab
+run bench_d512 --dim 512 --steps 100 --no-cpu --ab
+run bench_d1024 --dim 1024 --steps 100 --no-cpu --ab

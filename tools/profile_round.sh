@@ -9,13 +9,13 @@ export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --no-cpu --no-extras "$@" > $out/bench_stats.json 2> $out/stats.log || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --no-cpu --no-extras --min-seconds 0 "$@" > $out/bench_stats.json 2> $out/stats.log || exit 1
 echo "[profile] stats pass done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_on -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --nbatches 8 "$@" > $out/bench_fetch_on.json 2> $out/fetch_on.log || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_on -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 "$@" > $out/bench_fetch_on.json 2> $out/fetch_on.log || exit 1
 echo "[profile] FETCH_SIZE (bound on) done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_off -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --nbatches 8 --option block_bound=0 "$@" > $out/bench_fetch_off.json 2> $out/fetch_off.log || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_off -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --option block_bound=0 "$@" > $out/bench_fetch_off.json 2> $out/fetch_off.log || exit 1
 echo "[profile] FETCH_SIZE (bound off) done"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --nbatches 8 --streams 1 "$@" > $out/bench_sq.json 2> $out/sq.log || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --streams 1 "$@" > $out/bench_sq.json 2> $out/sq.log || exit 1
 echo "[profile] SQ pass done"
 python3 tools/profile_summary.py $out "$@" > $out/summary.md
 cat $out/summary.md

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/sq_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $out -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --nbatches 8 --streams 1 "$@" > $out/bench.json 2> $out/log || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $out -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --streams 1 "$@" > $out/bench.json 2> $out/log || exit 1
 python3 - $out <<'PY'
 import csv, glob, statistics, sys, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
