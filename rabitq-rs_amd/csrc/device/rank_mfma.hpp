@@ -605,7 +605,8 @@ __device__ __forceinline__ void sort_keys(uint64_t* keys, uint32_t n, uint32_t c
 }
 
 constexpr uint32_t kSelHead = 4;       // nearest lists that are always scored and scanned: their blocks give the bound T_ub
-constexpr uint32_t kSelTodoMax = 256;  // lists the lazy path scores beyond the head (more: the query takes the eager path)
+constexpr uint32_t kSelTodoMax = 512;  // lists the lazy path scores (more: the query takes the eager path)
+constexpr uint32_t kSelKeptMax = 256;  // scanned lists that are ordered through the side buffer (more: in-place compaction + sort)
 constexpr uint32_t kSelZoneMax = 1024; // boundary-zone lists whose membership the lazy path resolves by counting
 
 // dynamic LDS: keys[cap2] u64 | qrot[D] f32 | part[256] u32 | row[nlist] f32 (only when RM == 1) |
@@ -843,7 +844,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
         // when more than nprobe shortlist keys are <= tau (ties), else the smallest key above tau (both counted by the
         // shortlist pass).
         LSTAMP(0);
-        __shared__ uint32_t s_wmin[4][kSelHead];
+        __shared__ uint32_t s_wmin[4][kSelHead], s_todo[kSelTodoMax]; // s_todo: positions of the entries that need an exact score
         const uint32_t nown = (n + kThreads - 1 - tid) / kThreads; // entries tid, tid + 256, ... of this thread (n > tid)
         unsigned long long m_certain = 0ull, m_dead = 0ull, m_apx = 0ull;
         // what the classification (and the head selection) need of this thread's FIRST entry is requested now: one
@@ -991,7 +992,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             const float cost_maxh = key_to_float((int32_t)s_maxh);
             lazy = T_ub < INFINITY;
             dbg_tub = __float_as_uint(T_ub);
-            if (tid < h) hist[tid] = s_head[tid]; // (the candidate counts in `hist` have been read behind the barrier above)
+            if (tid < h) s_todo[tid] = s_head[tid];
             LSTAMP(3);
             if (lazy) {
                 // 3. classification of the entries beyond the head; what is alive goes straight to the to-score list (`hist`)
@@ -1014,7 +1015,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                     else {
                         if (!((m_certain >> u) & 1ull)) s_flag = 1u; // a zone list is alive
                         const uint32_t p = atomicAdd(&s_need, 1u);
-                        if (p < kSelTodoMax) hist[p] = i;
+                        if (p < kSelTodoMax) s_todo[p] = i;
                     }
                 }
                 __syncthreads();
@@ -1024,7 +1025,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                         const uint32_t i = tid + u * kThreads;
                         if (!is_head(i) && ((m_dead >> u) & 1ull) && !((m_certain >> u) & 1ull)) {
                             const uint32_t p = atomicAdd(&s_need, 1u);
-                            if (p < kSelTodoMax) hist[p] = i;
+                            if (p < kSelTodoMax) s_todo[p] = i;
                         }
                     }
                     __syncthreads();
@@ -1036,7 +1037,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                     // 4. score what is needed: the head and everything alive, in one round
                     const uint32_t m = s_need;
                     if (m) { // uniform
-                        auto todo_idx = [&](uint32_t j) { return hist[j]; };
+                        auto todo_idx = [&](uint32_t j) { return s_todo[j]; };
                         if (G.stage_rows && m <= 2u * G.stage_rows) canon_score_staged(keys, qrot, P.cent, D, metric, grow, m, tid, rows, G.stage_rows, todo_idx);
                         else {
                             if (m <= 64u) canon_score_octets(keys, qrot, P.cent, D, metric, grow, m, tid, todo_idx);
@@ -1049,7 +1050,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                     // membership: certain, or a scored zone list with fewer than nprobe - z0 smaller zone keys (the zone
                     // entries are marked in a bitset: only this — rare — step needs to know them from other threads)
                     __shared__ uint32_t s_zone[512];
-                    __shared__ unsigned long long s_kept[kSelTodoMax];
+                    __shared__ unsigned long long s_kept[kSelKeptMax];
                     if (zone_scored) {
                         for (uint32_t w = tid; w < 512; w += kThreads) s_zone[w] = 0u;
                         __syncthreads();
@@ -1073,7 +1074,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                         if (member && !dead) {
                             m_keep |= 1ull << u;
                             const uint32_t p = atomicAdd(&s_nk, 1u);
-                            if (p < kSelTodoMax) s_kept[p] = keys[i];
+                            if (p < kSelKeptMax) s_kept[p] = keys[i];
                         }
                         // vectors of the probe set: exact under diagnostics; for the profile's algorithmic bytes alone, the
                         // approximate probe set (the boundary zone is resolved only when something in it is alive)
@@ -1086,7 +1087,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                     if (dv) atomicAdd(&s_dead, dv);
                     if (mv) atomicAdd(&s_memvec, mv);
                     __syncthreads(); // the kept keys are complete (and every membership count has read the zone keys)
-                    if (s_nk <= kSelTodoMax) {
+                    if (s_nk <= kSelKeptMax) {
                         // the usual case, a handful of lists: rank sort from the side buffer straight into keys[0 .. m_scan)
                         m_scan = s_nk;
                         if (tid < m_scan) {

@@ -710,14 +710,18 @@ struct SortedRun {
 #define RBQ_WIN_GROW 4
 #endif
 #ifndef RBQ_WIN0
-#define RBQ_WIN0 kTileBlocks // stream entries examined by the first fill step
+#define RBQ_WIN0 kTB // stream entries examined by the first fill step (one tile's worth)
 #endif
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.
 // TR: registers per lane of the replay wave's top-k (1: top_k <= 63; 2: <= 128; 4: <= 256 — with more than one,
 // four waves per SIMD instead of five).
 template <int DT, int EX, int TR>
-__global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void k_scan(ScanParams P) {
+__global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) == 1) ? RBQ_SCAN_WAVES : 4)) void k_scan(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smraw[];
+    // blocks per scanner half-wave and tile: 1; a build option gives 2 at small dimensions (types.hpp: measured, not faster)
+    constexpr int NB = scan_nb((uint32_t)DT);
+    constexpr int kTB = kTileBlocks * NB;  // blocks per tile
+    constexpr int kTC = kTileCand * NB;    // candidates per tile
     const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
     const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
     uint8_t* s_lut = smraw;
@@ -732,13 +736,13 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         heap_d = reinterpret_cast<float*>(P.heap_ws + (size_t)blockIdx.x * 2 * ((size_t)P.top_k + 1));
         heap_s = reinterpret_cast<uint32_t*>(heap_d + (P.top_k + 1));
     }
-    float* q_lb = reinterpret_cast<float*>(q_slot + 2 * kTileCand);
-    float* q_ip = q_lb + 2 * kTileCand;
-    float* q_gadd = q_ip + 2 * kTileCand;
-    float* q_d = q_gadd + 2 * kTileCand;
-    uint32_t* s_list = reinterpret_cast<uint32_t*>(q_d + 2 * kTileCand); // [kTileCand] survivor positions, stream order
-    uint32_t* s_mask = s_list + kTileCand;                                // [2][kTileBlocks]
-    WorkItem* s_queue = reinterpret_cast<WorkItem*>(s_mask + 2 * kTileBlocks); // [kQueueCap] live blocks, stream order
+    float* q_lb = reinterpret_cast<float*>(q_slot + 2 * kTC);
+    float* q_ip = q_lb + 2 * kTC;
+    float* q_gadd = q_ip + 2 * kTC;
+    float* q_d = q_gadd + 2 * kTC;
+    uint32_t* s_list = reinterpret_cast<uint32_t*>(q_d + 2 * kTC); // [kTC] survivor positions, stream order
+    uint32_t* s_mask = s_list + kTC;                                // [2][kTB]
+    WorkItem* s_queue = reinterpret_cast<WorkItem*>(s_mask + 2 * kTB); // [kQueueCap] live blocks, stream order
     unsigned long long* s_fmask = reinterpret_cast<unsigned long long*>(s_queue + kQueueCap); // [kFillK][kNScan] fill-step live masks
     // no static __shared__ in this kernel: the dynamic region must start at LDS address 0 (see lds_lut_ptr)
     uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_fmask + kNScan * kFillK);
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
     auto refine_batch = [&](uint32_t buf, uint32_t nb, uint32_t g) {
         const uint32_t gl = tid & 15u;
         if (g < nb) {
-            const uint32_t e = buf * kTileCand + s_batch[g];
+            const uint32_t e = buf * kTC + s_batch[g];
             const uint32_t sl = q_slot[e];
             const uint8_t* ex = P.ex_codes + (size_t)sl * exb;
             float sacc;
@@ -832,8 +836,8 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         const uint32_t gl = tid & 15u;
         if (g >= nb) return;
         const bool has1 = g + ng < nb;
-        const uint32_t e0 = buf * kTileCand + s_batch[g];
-        const uint32_t e1 = buf * kTileCand + s_batch[has1 ? g + ng : g];
+        const uint32_t e0 = buf * kTC + s_batch[g];
+        const uint32_t e1 = buf * kTC + s_batch[has1 ? g + ng : g];
         const uint32_t sl0 = q_slot[e0], sl1 = q_slot[e1];
         const uint4* p0 = reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl0 * exb) + gl;
         const uint4* p1 = reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl1 * exb) + gl;
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
 #endif
   for (;;) { // a second pass only after a tie on the sorted fast path
     while (true) {
-        if (pos < ns && qcount < (uint32_t)kTileBlocks) {
+        if (pos < ns && qcount < (uint32_t)kTB) {
             // ---------------------------------------------------------------- fill step: examine `win` stream entries
             STAMP(st_c);
             if (scanner) {
@@ -1009,9 +1013,10 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
         if (qcount == 0) break;
         // -------------------------------------------------------------------- tile step
         STAMP(st_t0);
-        const uint32_t n = qcount < (uint32_t)kTileBlocks ? qcount : (uint32_t)kTileBlocks;
+        const uint32_t n = qcount < (uint32_t)kTB ? qcount : (uint32_t)kTB;
         const uint32_t buf = tile & 1u;
         if (scanner) {
+          if constexpr (NB == 1) { // one block per half-wave and tile
             WorkItem wi_c;
             wi_c.gblock = 0; wi_c.rank_nvalid = 0;
             if (hw < n) wi_c = s_queue[(qhead + hw) % kQueueCap];
@@ -1068,6 +1073,76 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                 q_gadd[e] = m_c.g_add;
                 q_d[e] = est;
             }
+          } else {
+            // half-wave hw scans blocks hw, hw + kTileBlocks, ... of the tile (NB of them); everything of all of them is requested
+            // before the first lookup
+            WorkItem wi_c[NB];
+            const uint8_t* blk[NB];
+            CodeRegs<DT> cc[NB];
+            Meta m_c[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const uint32_t bi = hw + (uint32_t)(kTileBlocks * i);
+                wi_c[i].gblock = 0; wi_c[i].rank_nvalid = 0;
+                if (bi < n) wi_c[i] = s_queue[(qhead + bi) % kQueueCap];
+                blk[i] = P.blocks + (size_t)wi_c[i].gblock * stride;
+                // The codes are requested together with the factor rows, not after the bound below: a queued block
+                // already passed the block-level bound of the fill step, so it is almost always still alive, and the
+                // two memory round trips overlap (the runtime-dimension path keeps the lazy order).
+                if (DT && bi < n) load_codes<DT>(cc[i], blk[i], l32);
+                if (bi < n) { ++p_meta; if (DT) ++p_code; }
+                m_c[i] = load_meta(wi_c[i]);
+            }
+            const float T = s_T;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const uint32_t bi = hw + (uint32_t)(kTileBlocks * i);
+                // per-lane bound with the fresh threshold: the whole wave may be prunable without looking anything up
+                const bool live_c = !bound_ok || (__ballot(lane_prunable(wi_c[i], m_c[i], T)) != ~0ull);
+                const uint32_t nvalid = wi_c[i].rank_nvalid & 63u;
+                const uint32_t slot = wi_c[i].gblock * 32u + l32;
+                bool valid = l32 < nvalid;
+                if (valid && P.filter) {
+                    const uint32_t id32 = (uint32_t)P.ids[slot];
+                    valid = ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
+                }
+                bool surv = false;
+                float lb = 0.0f, ip = 0.0f, est = 0.0f;
+#ifdef RBQ_STAMPS
+                ++st_ntile; if (!live_c) ++st_dead;
+#endif
+                if (live_c) { // wave-uniform
+                    STAMP(st_a);
+                    if (!DT && bi < n) ++p_code;
+                    const uint32_t accu = (DT ? lookup_codes<DT>(cc[i], blk[i], l32, lut0) : accumulate_block_rt(blk[i], lut0, l32, Dc)) & 0xffffu;
+#ifdef RBQ_STAMPS
+                    asm volatile("" :: "v"(accu));
+                    STAMP(st_b); st_look += st_b - st_a;
+#endif
+                    lb = lb_of(m_c[i], (float)accu, ip, est);
+                    if (P.mstg) {
+                        if (!finite_f(est)) valid = false;          // `if distance.is_finite()`
+                        if (P.metric == 0) est = fmaxf(est, 0.0f);  // distance.max(0.0)
+                        lb = est;                                   // f_error row and g_error are zero
+                    } else if (!finite_f(lb)) {
+                        lb = P.metric == 0 ? 0.0f : -(m_c[i].dotqc + qc.qnorm);
+                    }
+                    surv = valid && (lb < T);
+                }
+                if (valid && !surv) ++n_skip;
+                const unsigned long long bal = __ballot(surv);
+                const uint32_t mask32 = (uint32_t)(bal >> (half * 32));
+                if (l32 == 0) s_mask[buf * kTB + bi] = mask32;
+                if (surv) {
+                    const uint32_t e = buf * kTC + bi * 32u + l32;
+                    q_slot[e] = slot;
+                    q_lb[e] = lb;
+                    q_ip[e] = ip;
+                    q_gadd[e] = m_c[i].g_add;
+                    q_d[e] = est;
+                }
+            }
+          }
             STAMP(st_a);
             lds_barrier(); // A: this tile is published to the replay wave
 #ifdef RBQ_STAMPS
@@ -1076,7 +1151,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             if (fast && s_restart) break; // a tie was met: leave the pass now (every wave reads the flag behind the same barrier)
             uint32_t S = 0;
 #pragma unroll
-            for (int j = 0; j < kTileBlocks; ++j) S += __popc(s_mask[buf * kTileBlocks + j]);
+            for (int j = 0; j < kTB; ++j) S += __popc(s_mask[buf * kTB + j]);
 #ifdef RBQ_STAMPS
             st_surv += S;
 #endif
@@ -1108,15 +1183,15 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
             RSTAMP(rp_waitA);
             if (fast && s_restart) break;
             // compaction in stream order: block by block, lane order within the block
-            for (uint32_t b = half; b < (uint32_t)kTileBlocks; b += 2) {
+            for (uint32_t b = half; b < (uint32_t)kTB; b += 2) {
                 uint32_t base = 0;
-                for (uint32_t j = 0; j < b; ++j) base += __popc(s_mask[buf * kTileBlocks + j]);
-                const uint32_t m = s_mask[buf * kTileBlocks + b];
+                for (uint32_t j = 0; j < b; ++j) base += __popc(s_mask[buf * kTB + j]);
+                const uint32_t m = s_mask[buf * kTB + b];
                 if ((m >> l32) & 1u) s_list[base + __popc(m & ((1u << l32) - 1u))] = b * 32u + l32;
             }
             uint32_t S = 0;
 #pragma unroll
-            for (int j = 0; j < kTileBlocks; ++j) S += __popc(s_mask[buf * kTileBlocks + j]);
+            for (int j = 0; j < kTB; ++j) S += __popc(s_mask[buf * kTB + j]);
             S = __builtin_amdgcn_readfirstlane(S);
             const bool heavy = S > kLightMax;
             // Exact sequential replay of the reference's prune/push/pop loop in stream order, with LAZY refine:
@@ -1138,7 +1213,7 @@ __global__ __launch_bounds__(kScanThreads, (TR == 1 ? RBQ_SCAN_WAVES : 4)) void 
                     const uint32_t i = p + lane;
                     uint32_t e = 0;
                     float lbv = INFINITY;
-                    if (i < S) { e = buf * kTileCand + s_list[i]; lbv = q_lb[e]; }
+                    if (i < S) { e = buf * kTC + s_list[i]; lbv = q_lb[e]; }
                     const bool want = i < S && lbv < distk0;
                     const unsigned long long m = __ballot(want);
                     uint32_t np = p + 64u < S ? p + 64u : S;

@@ -119,7 +119,15 @@ constexpr int kTileCand = kTileBlocks * 32;     // candidates per tile
 constexpr int kFillK = RBQ_FILL_K;                 // stream entries per scanner lane and fill step
 constexpr int kWindow = kNScan * 64 * kFillK;      // largest fill window
 constexpr int kQueueCap = kTileBlocks - 1 + kWindow <= 512 ? 512 : 1024; // live-block FIFO (>= kTileBlocks - 1 + kWindow)
-static_assert(kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
+// blocks per scanner half-wave and tile of k_scan<DT, ...>: two for the compile-time dimensions up to 256 (DT = 0: runtime dimension)
+// (Measured in round 3 and left OFF: -DRBQ_SCAN_NB_MAXDIM=256 gives two blocks per half-wave and tile at D <= 256 — parity green,
+// but cfg2 (d = 128) 5.78 M queries/s against 6.25 M with one block, streaming roofline 0.312 against 0.318: the tile needs
+// 120 registers (4 waves per SIMD instead of 5) and the per-tile hand-over was not what bounds it.)
+#ifndef RBQ_SCAN_NB_MAXDIM
+#define RBQ_SCAN_NB_MAXDIM 0
+#endif
+__host__ __device__ constexpr int scan_nb(uint32_t DT) { return (DT != 0 && DT <= RBQ_SCAN_NB_MAXDIM) ? 2 : 1; }
+static_assert(2 * kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
 constexpr uint32_t kNprobeMax = 8192;             // largest nprobe of the MFMA-shortlist selector (2 x nprobe u64 keys in LDS); above it the
                                                   // exact all-pairs ranking with its key window in global memory serves the call
@@ -147,9 +155,10 @@ __host__ __device__ inline uint32_t ex_qlen(uint32_t D, uint32_t ex_bits) {
 //   list[kTileCand] u32 | mask[2][kTileBlocks] u32 | queue[kQueueCap] WorkItem | fmask[kNScan] u64 |
 //   T, len, nskip, nbatch | batch[kScanThreads/16] u32
 // (heap_in_lds = false: the heap lives in global memory, ScanParams::heap_ws)
-__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k, bool heap_in_lds = true) {
-    return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (heap_in_lds ? (size_t)(top_k + 1) * 8 : (size_t)0) + (size_t)kTileCand * 2 * 20 + kTileCand * 4 +
-           2 * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 8;
+// nb = scan_nb(DT) of the instantiation that will run
+__host__ __device__ inline size_t scan_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, uint32_t top_k, bool heap_in_lds = true, int nb = 1) {
+    return (size_t)Dc * 4 + (size_t)ex_qlen(D, ex_bits) * 4 + (heap_in_lds ? (size_t)(top_k + 1) * 8 : (size_t)0) + (size_t)nb * kTileCand * 2 * 20 +
+           (size_t)nb * kTileCand * 4 + 2 * (size_t)nb * kTileBlocks * 4 + kQueueCap * 8 + kNScan * kFillK * 8 + 32 + (kScanThreads / 16) * 8;
 }
 
 // ---- encoder ----------------------------------------------------------------------------------------------------

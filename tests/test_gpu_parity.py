@@ -637,7 +637,6 @@ def test_bench_rccl_single_rank_group():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["pruned"]["launches"] == 12 and d["recall_at_10"] > 0.9
     assert d["roofline"]["ids_identical_to_product_configuration"] and d["rccl_world_size"] == 1 and len(d["per_rank_queries_per_s"]) == 1
-    assert d["self_check"]["ids_identical"] and d["self_check"]["score_bits_identical"]
 
 
 def test_library_first_then_torch_in_a_fresh_process():
