@@ -10,9 +10,14 @@ Every step searches a DIFFERENT query batch: --nbatches (default 32) distinct ba
 steps walk through them round-robin, so no step finds its predecessor's code blocks or centroid rows in the cache
 (a serving workload never sees the same batch twice).
 
-Multi-GPU (--gpus N, launched with torch.distributed.run): index replicated per rank, each rank searches
-its own batches (weak scaling, no data-path collective), then ONE RCCL all_gather of the [batch][top_k]
-(id, score) blocks — the only exchange the path has.
+Multi-GPU (--gpus N): index replicated per rank, each rank searches its own batches (weak scaling, no data-path
+collective), then ONE RCCL all_gather of the [batch][top_k] (id, score) blocks per bucket of batches — the only exchange
+the path has.  `python bench.py --gpus N` starts its own N ranks (a child `torch.distributed.run`, before
+this process touches the GPU); under torch.distributed.run it runs as a rank.  --in-library: ONE process, ONE handle with
+N replicas, host buffers through rbq_search_batch (the reference's batch_search binding).
+
+The timed region of exactly K steps (barrier + synchronize on both sides, max over ranks) is repeated until
+--min-seconds (0.5 s) have been measured; `value` is the median region (`timed_regions`, `region_ms`).
 
 Prints one JSON line (rank 0).  What the objects mean:
   value / ms_per_step   whole path, queries and results resident in HBM, batches pipelined over --streams HIP streams
@@ -26,7 +31,11 @@ Prints one JSON line (rank 0).  What the objects mean:
   datasets              the low-intrinsic-dimension mixture (headline) and SURVEY 8d's isotropic mixture, each with recall,
                         rate and skip fraction
   cpu_baseline          the oracle (C restatement of the reference's AVX2/AVX-512 FastScan path) on the host cores: median
-                        of 3 all-core passes, plus the single-thread figure (how the reference times itself)
+                        of 3 passes on as many threads as the job's cgroup CPU quota, plus the single-thread figure (how the
+                        reference times itself)
+  latency               p50 / p99 of ONE rbq_search_batch call at nq in {1, 8, 64, 256} (page-locked buffers)
+  self_check            256 queries again with every shortcut off (exact all-pairs ranking, BinaryHeap emulation, no block
+                        bound): identical bits — the check that also covers indexes no CPU oracle run can (cfg5)
 """
 import argparse
 import json
