@@ -114,6 +114,7 @@ hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) 
     const size_t rowsN = RBQ_SEL_ROWS * ((size_t)p.D + 8) * 4 + 16;
     g.stage_rows = (p.lazy && lds + rowsN <= 64 * 1024) ? (uint32_t)RBQ_SEL_ROWS : 0u;
     if (g.stage_rows) lds += rowsN;
+    g.cand_cap = (uint32_t)(((g.stage ? (size_t)p.nprobe * 16 : 0) + (g.stage_rows ? rowsN - 16 : 0)) / 8); // (RM == 0 prefilter window)
     {   // diagnostic: extra dynamic LDS per workgroup (occupancy experiments)
         static const size_t pad = [] { const char* e = std::getenv("RBQ_SEL_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
         lds += pad;

@@ -367,6 +367,7 @@ struct SelectGeom {
     int row_in_lds;      // RM == 1: the approximate row is staged in LDS
     int stage;           // per-probe geometry staged in LDS
     uint32_t stage_rows; // centroid rows the LDS scorer stages at a time (0: no room, pair scorer only)
+    uint32_t cand_cap;   // RM == 0: (key, cid) candidates that fit the LDS behind `part` before it is used for anything else
 };
 
 // ---- canonical scores of shortlist entries ----------------------------------------------------------------------------
@@ -673,6 +674,10 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
     constexpr int KPT = 16;
     uint32_t kreg[KPT]; // RM == 2: ordered keys of elements (u>>2)*1024 + 4*tid + (u&3)
     bool bad_load = false;
+    // RM == 0 (more lists than fit registers or LDS: cfg5 has 65 536): candidate window, see the prefilter below
+    uint64_t* cand = reinterpret_cast<uint64_t*>(pgeo);
+    bool use_cand = false;
+    uint32_t n_cand = 0;
     // ordered 32-bit key of the approximate score (ascending = better)
     auto okey = [&](float s) -> uint32_t {
         int32_t k = total_key(s);
@@ -709,6 +714,8 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             }
         } else if (RM == 1) {
             for (uint32_t i = tid; i < nlist; i += kThreads) { const float v = lrow[i]; bad_load |= !finite_f(v); body(i, okey(v)); }
+        } else if (use_cand) { // RM == 0 after the prefilter: the few hundred lists that can matter, in LDS
+            for (uint32_t j = tid; j < n_cand; j += kThreads) { const uint64_t kc = cand[j]; body((uint32_t)kc, (uint32_t)(kc >> 32)); }
         } else {
             for (uint32_t i = tid; i < nlist; i += kThreads) { const float v = grow[i]; bad_load |= !finite_f(v); body(i, okey(v)); }
         }
@@ -724,35 +731,31 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
     // is the same for nearly all scores, which would serialise 4096 LDS atomics on one counter), the bin
     // holding rank k is found with a workgroup prefix sum, and [lo, hi] shrinks to that bin.
     bool all = nprobe >= nlist;
-    __shared__ uint32_t s_lo, s_hi, s_bin, s_cum, s_h, s_ng, s_w4[4];
-    if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0u; s_ng = 0u; }
-    __syncthreads();
-    {
-        uint32_t kmn = 0xffffffffu, kmx = 0u;
-        each_key([&](uint32_t, uint32_t key) {
-            kmn = key < kmn ? key : kmn;
-            kmx = key > kmx ? key : kmx;
-        });
-        const bool bad = bad_load;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            const uint32_t a = __shfl_xor(kmn, d, 64), b = __shfl_xor(kmx, d, 64);
-            kmn = a < kmn ? a : kmn;
-            kmx = b > kmx ? b : kmx;
+    __shared__ uint32_t s_lo, s_hi, s_bin, s_cum, s_h, s_ng, s_w4[4], s_nc;
+    // key of rank k (0-based, ascending) among the keys `each` enumerates: the range-adaptive radix select described above
+    auto kth_key = [&](auto&& each, uint32_t k) -> uint32_t {
+        if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0u; s_ng = 0u; }
+        __syncthreads();
+        {
+            uint32_t kmn = 0xffffffffu, kmx = 0u;
+            each([&](uint32_t, uint32_t key) {
+                kmn = key < kmn ? key : kmn;
+                kmx = key > kmx ? key : kmx;
+            });
+            const bool bad = bad_load;
+            kmn = wave_min_u32(kmn);
+            kmx = ~wave_min_u32(~kmx);
+            if ((tid & 63u) == 0) { atomicMin(&s_lo, kmn); atomicMax(&s_hi, kmx); }
+            if (bad) s_bad = 1;
         }
-        if ((tid & 63u) == 0) { atomicMin(&s_lo, kmn); atomicMax(&s_hi, kmx); }
-        if (bad) s_bad = 1;
-    }
-    __syncthreads();
-    uint32_t tau_key = 0;
-    if (!all) {
-        uint32_t lo = s_lo, hi = s_hi, k = nprobe - 1;
+        __syncthreads();
+        uint32_t lo = s_lo, hi = s_hi;
         while (true) {
             const uint32_t span = hi - lo;
             const uint32_t sh = span < 256u ? 0u : (32u - (uint32_t)__builtin_clz(span)) - 8u; // span >> sh in [128, 255]
             hist[tid] = 0;
             __syncthreads();
-            each_key([&](uint32_t, uint32_t key) {
+            each([&](uint32_t, uint32_t key) {
                 if (key - lo <= hi - lo) atomicAdd(&hist[(key - lo) >> sh], 1u); // lo <= key <= hi
             });
             __syncthreads();
@@ -765,22 +768,22 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             lo += s_bin << sh;
             const uint32_t width = (sh ? (1u << sh) : 1u) - 1u;
             if (hi - lo > width) hi = lo + width;
-            if (sh == 0) break; // lo is the key of rank nprobe-1
+            if (sh == 0) break; // lo is the key of rank k
             const uint32_t nc = s_h;
             if (nc <= (uint32_t)kThreads) {
                 // few candidates left (the usual case after ONE pass): gather them and take the one of rank k
                 // by counting — 3 barriers instead of 5 per further radix pass
-                uint32_t* cand = hist; // (every thread has read its bin count; this happens at most once)
-                each_key([&](uint32_t, uint32_t key) {
-                    if (key - lo <= hi - lo) cand[atomicAdd(&s_ng, 1u)] = key;
+                uint32_t* cnd = hist; // (every thread has read its bin count; this happens at most once)
+                each([&](uint32_t, uint32_t key) {
+                    if (key - lo <= hi - lo) cnd[atomicAdd(&s_ng, 1u)] = key;
                 });
                 __syncthreads();
                 if (tid < nc) {
-                    const uint32_t my = cand[tid];
+                    const uint32_t my = cnd[tid];
                     uint32_t less = 0, eq = 0;
 #pragma unroll 8
                     for (uint32_t j = 0; j < nc; ++j) {
-                        const uint32_t kj = cand[j];
+                        const uint32_t kj = cnd[j];
                         less += kj < my ? 1u : 0u;
                         eq += kj == my ? 1u : 0u;
                     }
@@ -791,22 +794,75 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 break;
             }
         }
-        tau_key = lo;
+        __syncthreads(); // (the shared scratch may be reused by the next call)
+        return lo;
+    };
+    const QueryConsts qc = P.consts[q];
+    const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + P.cnorm2_max) * 1.001f;
+    // ordered key of (the score of `key` moved 2 eps towards worse); 0xffffffff if that is not finite
+    auto widen = [&](uint32_t key) -> uint32_t {
+        int32_t k = (int32_t)(key ^ 0x80000000u);
+        if (metric == 1) k = ~k;
+        const float sc = key_to_float(k);
+        const float lim = metric == 0 ? sc + 2.0f * eps : sc - 2.0f * eps;
+        return finite_f(lim) ? okey(lim) : 0xffffffffu;
+    };
+    // Prefilter for RM == 0 (n_lists beyond registers and LDS): every pass over the row costs 4 * n_lists bytes of global
+    // reads and n_lists LDS atomics per query (cfg5, 65 536 lists: the selection was 13 of the step's 24 ms).  Pass A keeps
+    // each thread's KL smallest keys in registers; the nprobe-th smallest B of those 256 * KL keys bounds tau from above
+    // (at least nprobe keys of the row are <= B).  Pass B gathers the (key, cid) of every list within 2 eps beyond B into
+    // LDS: a superset of the shortlist (tau + 2 eps <= B + 2 eps).  Everything after that — the exact tau, the shortlist, the
+    // counts — enumerates these few hundred candidates instead of the row.
+    constexpr int KL = 8;
+    if (RM == 0 && !all && G.cand_cap >= 4u * nprobe && 2u * nprobe <= (uint32_t)(kThreads * KL)) {
+        uint32_t lk[KL];
+#pragma unroll
+        for (int u = 0; u < KL; ++u) lk[u] = 0xffffffffu;
+        for (uint32_t i = tid; i < nlist; i += kThreads) {
+            const float v = grow[i];
+            bad_load |= !finite_f(v);
+            const uint32_t key = okey(v);
+            if (key < lk[KL - 1]) { // insertion into the ascending register list
+                lk[KL - 1] = key;
+#pragma unroll
+                for (int u = KL - 1; u > 0; --u) {
+                    const uint32_t a = lk[u - 1], b = lk[u];
+                    lk[u - 1] = a < b ? a : b;
+                    lk[u] = a < b ? b : a;
+                }
+            }
+        }
+        const uint32_t B = kth_key([&](auto&& body) {
+#pragma unroll
+            for (int u = 0; u < KL; ++u) if (lk[u] != 0xffffffffu) body(0u, lk[u]);
+        }, nprobe - 1);
+        const uint32_t cutB = widen(B);
+        if (tid == 0) s_nc = 0;
+        __syncthreads();
+        if (cutB != 0xffffffffu && s_bad == 0) {
+            for (uint32_t i = tid; i < nlist; i += kThreads) {
+                const uint32_t key = okey(grow[i]);
+                if (key <= cutB) {
+                    const uint32_t pp = atomicAdd(&s_nc, 1u);
+                    if (pp < G.cand_cap) cand[pp] = ((uint64_t)key << 32) | i;
+                }
+            }
+            __syncthreads();
+            n_cand = s_nc;
+            use_cand = n_cand <= G.cand_cap && n_cand >= nprobe;
+        }
+        __syncthreads();
+    }
+    uint32_t tau_key = 0;
+    if (!all) tau_key = kth_key(each_key, nprobe - 1);
+    else { // (non-finite scores must still be seen)
+        each_key([&](uint32_t, uint32_t) {});
+        if (bad_load) s_bad = 1;
+        __syncthreads();
     }
     SSTAMP(); // 2: radix select done
     // 2. shortlist: approximate score within 2*eps of tau
-    const QueryConsts qc = P.consts[q];
-    const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + P.cnorm2_max) * 1.001f;
-    uint32_t cut = 0xffffffffu;
-    if (!all) {
-        // back from ordered key to the score value
-        int32_t k = (int32_t)(tau_key ^ 0x80000000u);
-        if (metric == 1) k = ~k;
-        const float tau = key_to_float(k);
-        const float lim = metric == 0 ? tau + 2.0f * eps : tau - 2.0f * eps;
-        cut = okey(lim);
-        if (!finite_f(lim)) cut = 0xffffffffu;
-    }
+    const uint32_t cut = all ? 0xffffffffu : widen(tau_key);
     __shared__ uint32_t s_cntle, s_minab; // keys <= tau (more than nprobe: ties at tau) / smallest key above tau
     for (uint32_t i = tid; i < cap2; i += kThreads) keys[i] = ~0ull;
     __shared__ uint32_t s_z0, s_tub, s_flag, s_need, s_dead, s_maxh, s_nh, s_nk, s_head[kSelHead]; // (s_tub, s_maxh: total_cmp keys of floats)
