@@ -14,7 +14,8 @@ assert hasattr(oracle, "search_batch"), "wrong `oracle` module on sys.path: %r" 
 import test_gpu_parity as t
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
-wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties", "lists", "threads")
+wide = len(sys.argv) > 3 and sys.argv[3] in ("wide", "streams", "mstg", "ties", "lists", "threads", "lazy")
+lazy_mode = len(sys.argv) > 3 and sys.argv[3] == "lazy"
 threads_mode = len(sys.argv) > 3 and sys.argv[3] == "threads"
 lists_mode = len(sys.argv) > 3 and sys.argv[3] == "lists"
 ties_mode = len(sys.argv) > 3 and sys.argv[3] == "ties"
@@ -228,6 +229,49 @@ def run_streams(seed):
     idx.close()
 
 
+def lazy_case(seed):
+    """In-distribution queries (perturbed data points: the lists near a query are really near, the far ones are dropped by the
+    lazy probe selection) over both metrics, raw and normalised inner product, all bit widths, clustered and uniform data,
+    large nprobe, top_k from 1 to past what the head lists hold; the queries of every other mode come from a different
+    mixture and drop nothing."""
+    rng = np.random.default_rng(seed)
+    rot = int(rng.integers(0, 5) != 0)
+    dim = int(rng.choice([16, 40, 64, 100, 128, 200, 256, 384, 512, 768, 960, 1024, 1536])) if rot == 1 else int(rng.choice([16, 32, 64, 96, 128]))
+    nlist = int(rng.choice([8, 20, 50, 100, 200, 300, 600, 1000, 4097, 17000]))
+    nmax = max(nlist * 3, min(40000, 8_000_000 // dim))
+    n = int(rng.integers(nlist * 2, nmax))
+    if nlist >= 4097:
+        dim = min(dim, 128)
+        n = int(nlist * rng.choice([2, 3]))
+    return dict(rot=rot, dim=dim, nlist=nlist, n=n, bits=int(rng.choice([1, 3, 7])), metric=int(rng.integers(0, 2)),
+                raw_ip=bool(rng.integers(0, 3) == 0), uniform=bool(rng.integers(0, 8) == 0), nq=int(rng.integers(1, 48)),
+                top_k=int(rng.choice([1, 2, 5, 10, 10, 17, 64, 100, 200, 300, 1000])),
+                nprobe=int(min(nlist, rng.choice([1, 2, 4, 8, 16, 32, 64, 128, 300, 600, 2000]))),
+                noise=float(rng.choice([0.0, 0.01, 0.05, 0.2, 1.0])), gen=int(rng.choice([2, 4, 8, 50])))
+
+
+def run_lazy(seed):
+    import rabitq_rs_amd as rq
+    c = lazy_case(seed)
+    norm = c["metric"] == 1 and not c["raw_ip"]
+    data = conftest.make_dataset(c["n"], c["dim"], max(c["nlist"] // c["gen"], 1), seed, normalize=norm, uniform=c["uniform"])
+    data, built = conftest.build_index(n=c["n"], dim=c["dim"], nlist=c["nlist"], total_bits=c["bits"], metric=c["metric"],
+                                       rotator=c["rot"], seed=seed, data=data)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(seed + 11)
+    q = data[rng.integers(0, c["n"], c["nq"])] + c["noise"] * rng.standard_normal((c["nq"], c["dim"])).astype(np.float32)
+    if norm:
+        q = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-20)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    ids, sc, cnt = t._compare(built, idx, q, c["top_k"], c["nprobe"])
+    idx.set_option("lazy_select", 0)
+    ids2, sc2, cnt2, _ = idx.batch_search_raw(q, rq.SearchParams(c["top_k"], c["nprobe"]))
+    assert np.array_equal(ids2, ids) and np.array_equal(cnt2, cnt) and np.array_equal(sc2.view(np.uint32), sc.view(np.uint32)), "eager selection differs"
+    stats["queries"] += len(q)
+    stats["results"] += int(cnt.sum())
+    idx.close()
+
+
 def run_wide(seed):
     import rabitq_rs_amd as rq
     c = wide_case(seed)
@@ -276,7 +320,9 @@ bad, harness = [], []
 t0 = time.time()
 for seed in range(first, last):
     try:
-        if threads_mode:
+        if lazy_mode:
+            run_lazy(seed)
+        elif threads_mode:
             run_threads(seed)
         elif lists_mode:
             run_lists(seed)
@@ -294,10 +340,10 @@ for seed in range(first, last):
     except AssertionError:
         bad.append(seed)
         harness = []
-        print("MISMATCH seed", seed, (threads_case(seed) if threads_mode else lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
+        print("MISMATCH seed", seed, (lazy_case(seed) if lazy_mode else threads_case(seed) if threads_mode else lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), traceback.format_exc().splitlines()[-1][:300], flush=True)
     except Exception:
         msg = traceback.format_exc().splitlines()[-1][:300]
-        print("ERROR seed", seed, (threads_case(seed) if threads_mode else lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
+        print("ERROR seed", seed, (lazy_case(seed) if lazy_mode else threads_case(seed) if threads_mode else lists_case(seed) if lists_mode else ties_case(seed) if ties_mode else mstg_case(seed) if mstg_mode else streams_case(seed) if streams_mode else wide_case(seed)) if wide else t._random_case(seed), msg, flush=True)
         if os.environ.get("SOAK_TB"):
             traceback.print_exc()
         harness.append(msg)

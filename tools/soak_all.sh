@@ -10,3 +10,4 @@ run mstg $((b+2000)) $((b+2200))
 run lists $((b+3000)) $((b+3100))
 run streams $((b+4000)) $((b+4060))
 run threads $((b+5000)) $((b+5060))
+run lazy $((b+6000)) $((b+6300))
