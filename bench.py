@@ -49,8 +49,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The HIP runtime multiplexes a process's streams over 4 hardware queues by default; two of the batch streams on one
-# queue serialise their kernels.  Eight queues let every batch stream have its own (set before HIP starts).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# queue serialise their kernels.  Sixteen queues let every batch stream have its own (set before HIP starts; round 3,
+# headline: 8 queues / 6 streams 7.05 M, 16 / 12 7.5 M queries/s at --steps 96; 32 queues hung a box once — not used).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 HEADLINE = dict(n=1_000_000, dim=960, nlist=4096, nprobe=128, bits=7, metric=0, batch=1024, top_k=10)
@@ -94,7 +95,7 @@ def parse():
                          "(indexes whose raw vectors exceed HBM: cfg5)")
     ap.add_argument("--kmeans-iters", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], help="rbq_debug_set_option name=value (diagnostic A/B runs)")
-    ap.add_argument("--streams", type=int, default=6, help="HIP streams the batches are issued on, round-robin (tools/streams_sweep.py)")
+    ap.add_argument("--streams", type=int, default=12, help="HIP streams the batches are issued on, round-robin (tools/streams_sweep.py)")
     ap.add_argument("--config", default=None, choices=sorted(PRESETS),
                     help="a BASELINE.json configuration by name (sets n/dim/nlist/nprobe/bits/metric/batch/top-k; explicit flags win)")
     ap.add_argument("--min-seconds", type=float, default=0.5,

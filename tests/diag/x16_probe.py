@@ -4,7 +4,7 @@ variant (RBQ_LIB_PATH).  python tests/diag/x16_probe.py [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, torch
 import bench
 import rabitq_rs_amd as rq

@@ -3,7 +3,7 @@ RBQ_LIB_PATH=<x16 variant> this is the combination rank_mfma.hpp describes.  pyt
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import __graft_entry__ as g
 g.build_cpu_libs()
 import rabitq_rs_amd as rq

@@ -4,7 +4,7 @@ kernel trace of the same process (run under `rocprofv3 --kernel-trace --output-f
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, torch
 import bench
 import rabitq_rs_amd as rq

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 import bench  # noqa: E402
 import rabitq_rs_amd as rq  # noqa: E402
@@ -79,6 +79,10 @@ def run(batch, configs):
                 lib.rbq_host_free(p)
 
 
+if os.environ.get("HOST_SWEEP_BIG") == "1":  # large calls: how many lanes pay
+    run(8192, ((1024, 4), (1024, 6), (1024, 8), (1024, 12), (512, 12), (2048, 4), (0, 0)))
+    run(4096, ((1024, 4), (512, 6), (512, 8), (0, 0)))
+    sys.exit(0)
 run(1024, ((1024, 1), (512, 2), (256, 4), (0, 0)))
 run(4096, ((4096, 1), (1024, 4), (1024, 2), (2048, 2), (512, 4), (0, 0)))
 run(256, ((0, 0),))

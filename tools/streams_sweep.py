@@ -1,6 +1,6 @@
 """Diagnostic: throughput of rbq_search_batch_device against the number of caller streams (no profiling taps)."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
