@@ -20,7 +20,7 @@ else:  # large index: the device encoder (a small CPU build only supplies the he
     del x
 qs = [mix.draw(a.batch, 20260102 + i).cpu().numpy() for i in range(3)]
 idx.set_option('host_subbatch', 1 << 20)  # one sub-batch: the diag slots carry the stamps of one launch
-for q in qs:  # the last batch is cold: nothing of it is in the caches
+for q in qs + ([qs[-1]] if os.environ.get('STAMPS_WARM') == '1' else []):  # the last batch is cold: nothing of it is in the caches (STAMPS_WARM=1: run it again, warm)
     ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
 d = diag.astype(np.uint64)
 if os.environ.get('RBQ_STAMPS_MODE') == '3':
