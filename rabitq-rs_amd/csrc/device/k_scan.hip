@@ -1,4 +1,5 @@
 // k_scan.hip — translation unit of the roofline kernel (scan.hpp) and its launcher.  gfx950 only.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -64,7 +65,9 @@ hipError_t launch_scan_more_dims(const ScanParams& P, uint32_t nq, size_t lds, i
 hipError_t launch_scan(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const uint32_t D = P.D, Dc = P.Dc;
     const int nb = D == Dc ? scan_nb(D == 128 || D == 256 || D == 384 || D == 512 || D == 768 || D == 960 || D == 1024 || D == 1536 ? D : 0u) : 1;
-    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, P.top_k, P.heap_ws == nullptr, nb);
+    // (RBQ_SCAN_LDS_PAD: diagnostic — extra dynamic LDS per workgroup, occupancy experiments)
+    static const size_t pad = [] { const char* e = std::getenv("RBQ_SCAN_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+    const size_t lds = scan_lds_bytes(Dc, D, P.ex_bits, P.top_k, P.heap_ws == nullptr, nb) + pad;
     if (D == Dc && D == 960) return launch_scan_d<960>(P, nq, lds, device, s, ev0, ev1);
     if (D == Dc && D == 768) return launch_scan_d<768>(P, nq, lds, device, s, ev0, ev1);
     if (D == Dc && D == 128) return launch_scan_d<128>(P, nq, lds, device, s, ev0, ev1);
