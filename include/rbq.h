@@ -93,7 +93,10 @@ typedef struct {
  * n_devices >= 1 replicas: devices[i] = HIP device ordinal of replica i (NULL = the current device for one
  * replica, devices 0..n-1 otherwise; an ordinal may repeat).  Replica 0 is built from the host arrays, the others
  * are device-to-device copies of it.  `rbq_search_batch` shards a batch over the replicas (the reference's
- * batch_search is a par_iter over queries, src/ivf.rs:1743-1752).  Inputs are copied; nothing is retained. */
+ * batch_search is a par_iter over queries, src/ivf.rs:1743-1752).  Inputs are copied; nothing is retained.
+ * Test status: several replicas on ONE device (a repeated ordinal) are covered by the GPU suite; replicas on DISTINCT
+ * devices (peer copy or pinned bounce, per-device launch state) have only run where tests/test_gpu_round3.py::
+ * test_replicas_on_two_devices found two GPUs — the builder's boxes had one. */
 int rbq_index_create(const rbq_header* hdr, const rbq_list_view* lists,
                      int n_devices, const int* devices, rbq_index** out);
 

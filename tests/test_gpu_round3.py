@@ -184,3 +184,32 @@ def test_scan_dimension_instantiations(dim, bits, metric):
     for top_k, nprobe in ((10, 8), (100, 12), (200, 32)):
         _compare(built, idx, q, top_k, nprobe)
     idx.close()
+
+
+# ---- replicas on DISTINCT devices: runs only where the box has two GPUs -------------------------------
+def test_replicas_on_two_devices():
+    """devices = [0, 1]: the second replica is a cross-device copy (peer copy, or the pinned bounce when the devices cannot
+    reach each other), every replica launches on its own device with its own LDS attribute cache, and caller buffers are
+    reached from both.  Skipped on a one-GPU box — until it has run somewhere, N distinct devices are covered by code review
+    and by the [0, 0] tests only (include/rbq.h says so)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    data, built = build_index(n=9000, dim=128, nlist=64, total_bits=7, seed=201)
+    one = rq.IvfRabitqIndex.from_built(built)
+    two = rq.IvfRabitqIndex.from_built(built, devices=[0, 1])
+    assert two.device_count() == 2
+    rng = np.random.default_rng(77)
+    q = np.ascontiguousarray(data[rng.choice(9000, 333, replace=False)] + 0.05 * rng.standard_normal((333, 128)).astype(np.float32))
+    for top_k, nprobe in ((10, 16), (100, 8), (5000, 64)):  # (5000: the large-LDS heap — the LDS limit is raised per device)
+        ids, sc, cnt = _compare(built, two, q, top_k, nprobe)
+        ids1, sc1, cnt1, _ = one.batch_search_raw(q, rq.SearchParams(top_k, nprobe))
+        assert np.array_equal(ids, ids1) and np.array_equal(cnt, cnt1) and np.array_equal(sc.view(np.uint32), sc1.view(np.uint32))
+    ln = one.debug_copy_index("list_n", np.empty(64, np.uint32))
+    nblocks = int(((ln + 31) // 32).sum())
+    two.set_option("debug_replica", 1)
+    for name, nbytes in (("blocks", nblocks * (128 * 4 + 384)), ("ids", nblocks * 32 * 8), ("bsum", nblocks * 32), ("centroids", 64 * 128 * 4)):
+        a = one.debug_copy_index(name, np.empty(nbytes, np.uint8))
+        b = two.debug_copy_index(name, np.empty(nbytes, np.uint8))
+        assert np.array_equal(a, b), name
+    one.close(); two.close()
