@@ -67,7 +67,7 @@ struct SelectParams {
     uint64_t wl_stride;
     uint32_t* nstream;
     unsigned long long* nvec;
-    unsigned long long* prof_total; // null unless a profile is open
+    unsigned long long* prof_total; // null unless a profile is open: slot kProfVectorsProbed of the striped counters (types.hpp)
     unsigned int* fallback_count;
     int force_fallback;
     const BlockSummary* bsum;

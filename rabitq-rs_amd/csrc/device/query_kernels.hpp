@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kThreads) void k_select(const float* __restrict__ s
         for (uint32_t i = 0; i < kThreads; ++i) { uint32_t v = part[i]; part[i] = run; run += v; }
         nstream[q] = run;
         nvec_probed[q] = s_nvec; // sum of n_c over the probed lists: the scan's algorithmic work
-        if (prof_total) atomicAdd(prof_total, s_nvec);
+        if (prof_total) atomicAdd(prof_total + prof_stripe(q), s_nvec);
     }
     __syncthreads();
     uint64_t pos = (uint64_t)q * wl_stride + part[tid];

@@ -1333,7 +1333,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
         // vectors of the probed lists (the scan's algorithmic work): scanned + dead members (exact when exact_members)
         const unsigned long long nv = np == nprobe ? s_nvec : s_memvec;
         P.nvec[q] = nv;
-        if (P.prof_total) atomicAdd(P.prof_total, nv);
+        if (P.prof_total) atomicAdd(P.prof_total + prof_stripe(q), nv);
         if (P.dead_skipped) { // [1]: lists that go to the scan; [2], [3]: diagnostics taps of the lazy selection
             P.dead_skipped[q] = dead_vec; P.dead_skipped[P.nq + q] = np;
             P.dead_skipped[2 * (size_t)P.nq + q] = dbg_tub; P.dead_skipped[3 * (size_t)P.nq + q] = dbg_z;

@@ -169,6 +169,8 @@ struct Replica {
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
+    bool profile_counters = true; // an open profile keeps the traffic counters (option profile_counters = 0: stage timings only —
+                                  // the counters cost the pipelined run 2-3 %, bench.py collects them in a pass of their own)
     // host
     std::vector<uint32_t> h_list_n;
     std::vector<uint64_t> nblk_desc_prefix; // prefix sums of per-list block counts sorted descending
@@ -365,8 +367,8 @@ int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
                                   (BlockSummaryEx*)ix->bsumx.p, (BlockSummary*)ix->lsum.p, 0));
     if ((rc = alloc_arr(ix->fallbacks, 8))) return rc;   // [0] rank fallbacks, [1] heap restarts
     HIP_TRY(hipMemset(ix->fallbacks.p, 0, 8));
-    if ((rc = alloc_arr(ix->prof, kProfSlots * 8))) return rc;
-    HIP_TRY(hipMemset(ix->prof.p, 0, kProfSlots * 8));
+    if ((rc = alloc_arr(ix->prof, (size_t)kProfStripes * kProfSlots * 8))) return rc;
+    HIP_TRY(hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8));
     const char* e = std::getenv("RBQ_EXACT_RANK");
     ix->exact_rank = e && e[0] == '1';
     const char* f = std::getenv("RBQ_FORCE_RANK_FALLBACK");
@@ -417,7 +419,7 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
     ix->dim = src->dim; ix->D = src->D; ix->Dc = src->Dc; ix->metric = src->metric; ix->rotator = src->rotator; ix->ex_bits = src->ex_bits;
     ix->n_vectors = src->n_vectors; ix->n_lists = src->n_lists; ix->n_blocks = src->n_blocks; ix->trunc = src->trunc; ix->fac = src->fac;
     ix->cnorm2_max = src->cnorm2_max; ix->h_list_n = src->h_list_n; ix->nblk_desc_prefix = src->nblk_desc_prefix;
-    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select;
+    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select; ix->profile_counters = src->profile_counters;
     for (size_t i = 0; i < sizeof(ix->arrays) / sizeof(ix->arrays[0]); ++i) {
         const Arr* s = src->arrays[i];
         Arr* d = ix->arrays[i];
@@ -428,7 +430,7 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
         d->bytes = s->bytes;
     }
     hipError_t e = hipMemset(ix->fallbacks.p, 0, 8);
-    if (e == hipSuccess) e = hipMemset(ix->prof.p, 0, kProfSlots * 8);
+    if (e == hipSuccess) e = hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8);
     if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, hipGetErrorString(e)); }
     *out = ix;
     return RBQ_OK;
@@ -983,7 +985,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.exact_heap = ix->exact_heap ? 1u : 0u;
     P.heap_restarts = (unsigned int*)ix->fallbacks.p + 1;
     P.mstg = mstg ? 1u : 0u;
-    P.prof = ix->profiling ? (unsigned long long*)ix->prof.p : nullptr;
+    P.prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
@@ -1026,7 +1028,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         if ((rc = w->rot_hi.ensure(nq * D * 2))) return rc;
         if ((rc = w->rot_lo.ensure(nq * D * 2))) return rc;
     }
-    unsigned long long* prof = ix->profiling ? (unsigned long long*)ix->prof.p : nullptr;
+    unsigned long long* prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     {
         ProfScope ps(ix, 0, stream);
         PrepParams p;
@@ -1613,7 +1615,7 @@ void rbq_profile_begin(rbq_index* h) {
             sp.ev.clear(); sp.ms = 0; sp.launches = 0; sp.samples.clear();
         }
         for (auto& c : ix->prof_counters) c = 0;
-        (void)hipMemset(ix->prof.p, 0, kProfSlots * 8);
+        (void)hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8);
         ix->profiling = true;
     }
 }
@@ -1624,9 +1626,12 @@ void rbq_profile_end(rbq_index* h) {
         (void)hipDeviceSynchronize();
         std::lock_guard<std::mutex> lk(ix->mu);
         ix->profiling = false;
-        unsigned long long c[kProfSlots] = {0};
-        (void)hipMemcpy(c, ix->prof.p, kProfSlots * 8, hipMemcpyDeviceToHost);
-        for (int i = 0; i < kProfSlots; ++i) ix->prof_counters[i] = c[i];
+        std::vector<unsigned long long> c((size_t)kProfStripes * kProfSlots, 0ull);
+        (void)hipMemcpy(c.data(), ix->prof.p, c.size() * 8, hipMemcpyDeviceToHost);
+        for (int i = 0; i < kProfSlots; ++i) {
+            ix->prof_counters[i] = 0;
+            for (uint32_t st = 0; st < kProfStripes; ++st) ix->prof_counters[i] += c[(size_t)st * kProfSlots + i];
+        }
         for (auto& sp : ix->stage_prof) {
             for (auto& e : sp.ev) {
                 float ms = 0;
@@ -1684,6 +1689,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "exact_rank")) ix->exact_rank = value != 0;
         else if (!std::strcmp(name, "exact_heap")) ix->exact_heap = value != 0;
         else if (!std::strcmp(name, "lazy_select")) ix->lazy_select = value != 0;
+        else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;
         else if (!std::strcmp(name, "f32_rank")) ix->f32_rank = value != 0;
         else if (!std::strcmp(name, "wg_prep")) ix->wg_prep = value != 0;
         else if (!std::strcmp(name, "small_rank_tiles")) ix->small_rank_tiles = value != 0;

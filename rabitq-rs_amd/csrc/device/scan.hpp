@@ -1447,12 +1447,13 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
     __syncthreads();
     if (P.prof) {
         if (tid == 0) {
-            atomicAdd(P.prof + kProfCodeBlocks, (unsigned long long)s_misc[5]);
-            atomicAdd(P.prof + kProfMetaBlocks, (unsigned long long)s_misc[6]);
-            atomicAdd(P.prof + kProfStreamEntries, (unsigned long long)ns * p_pass);
-            atomicAdd(P.prof + kProfQueries, 1ull);
+            unsigned long long* pc = P.prof + prof_stripe(q);
+            atomicAdd(pc + kProfCodeBlocks, (unsigned long long)s_misc[5]);
+            atomicAdd(pc + kProfMetaBlocks, (unsigned long long)s_misc[6]);
+            atomicAdd(pc + kProfStreamEntries, (unsigned long long)ns * p_pass);
+            atomicAdd(pc + kProfQueries, 1ull);
         }
-        if (wave == (uint32_t)kNScan && lane == 0 && ex_bits) atomicAdd(P.prof + kProfExEvals, (unsigned long long)s_misc[7]);
+        if (wave == (uint32_t)kNScan && lane == 0 && ex_bits) atomicAdd(P.prof + prof_stripe(q) + kProfExEvals, (unsigned long long)s_misc[7]);
     }
     const uint32_t len = s_len;
     for (uint32_t i = tid; i < top_k; i += kScanThreads) {

@@ -97,7 +97,7 @@ struct ScanParams {
     unsigned int* heap_restarts; // counter of queries re-run with the exact heap after a distance tie (or null)
     uint32_t mstg;           // MSTG posting-list semantics (src/mstg/index.rs:216-330): distance = binary estimate,
                              // non-finite dropped, L2 clamped to >= 0, no error-bound term
-    unsigned long long* prof; // null, or the traffic counters of kProf* below (one atomicAdd per workgroup at exit)
+    unsigned long long* prof; // null, or the traffic counters [kProfStripes][kProfSlots] of kProf* below (added once per workgroup, at exit)
     uint32_t* heap_ws;            // null, or [nq][2 * (top_k + 1)] words: the exact heap in global memory (top_k beyond the LDS)
     const uint32_t* dead_skipped; // [nq] vectors of probed lists that the probe selection proved skipped as a whole (they
                                   // never enter the stream; diagnostics add them to skipped_by_lower_bound), or null
@@ -105,6 +105,10 @@ struct ScanParams {
 // traffic counters kept while a profile is open (rbq_profile_begin/end); [0] is written by the select kernels
 enum { kProfVectorsProbed = 0, kProfCodeBlocks = 1, kProfMetaBlocks = 2, kProfStreamEntries = 3, kProfExEvals = 4,
        kProfQueries = 5, kProfSlots = 8 };
+// The counters are kept in kProfStripes copies (one 64-byte line each), a query adds to copy (query index mod kProfStripes) and
+// the host sums them: six atomics per query on ONE address serialise in the L2 and were 9 % of the pipelined rate (round 3).
+constexpr uint32_t kProfStripes = 64;
+__host__ __device__ inline uint32_t prof_stripe(uint32_t q) { return (q % kProfStripes) * (uint32_t)kProfSlots; }
 
 #ifndef RBQ_NSCAN
 #define RBQ_NSCAN 3         // scanner waves per workgroup (3 + replay wave = 256 threads: 4 workgroups per CU)
