@@ -37,9 +37,10 @@ if b:
 
 print("## `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --no-cpu --no-extras`\n")
 ns = b["config"]["streams"] if b else "N"
-print(f"One process: {ns} setup + 8 warm-up + 20 timed steps on {ns} streams (bound on, every step a different batch), 32 single-stream "
-      "verification launches, then the roofline leg (bound off: 1 + 2 + 6 + 2 launches on one stream).  avg mixes those; min = the "
-      "kernel alone on the chip (warm: a verification launch right after the same batch's timed step).\n")
+print(f"One process: {ns} setup + 8 warm-up + 20 timed steps on {ns} streams (bound on, every step a different batch; traffic counters off), "
+      f"{ns} setup + 32 launches of the counter pass (the same batches, counters on), 32 single-stream verification launches, then the "
+      "roofline leg (bound off: 1 + 2 + 6 + 2 launches on one stream).  avg mixes those; min = the kernel alone on the chip (warm: a "
+      "verification launch right after the same batch's counter-pass launch).\n")
 print("| kernel | calls | avg ms | min ms | max ms | share |\n|---|---|---|---|---|---|")
 rows = []
 for f in glob.glob(f"{d}/stats/**/*kernel_stats.csv", recursive=True):
