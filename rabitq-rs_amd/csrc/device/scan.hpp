@@ -1269,6 +1269,16 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
                     bool tie = false;
                     int dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
+                    if (!count_skips && len_s == top_k) {
+                        // One data-parallel test in front of the serial loop (lane j = candidate j): the threshold only falls
+                        // inside the batch, so a candidate whose lower bound or whose distance is not below the threshold
+                        // at the START of the batch is skipped or rejected by the reference as well (an EQUAL distance stays in:
+                        // the serial loop must report the tie).  Once the run is full most of a batch ends here.
+                        const int kk0 = HeapOps::key(dk);
+                        const bool pass = (bt.mt >> lane) & 1ull && __int_as_float(bt.v_lb) < __int_as_float(dk) &&
+                                          (v_d & 0x7f800000) != 0x7f800000 && HeapOps::key(v_d) <= kk0;
+                        todo = __ballot(pass);
+                    }
                     while (todo) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(todo);
                         todo &= todo - 1ull;
