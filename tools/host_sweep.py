@@ -1,5 +1,6 @@
 """PCIe-inclusive rate of rbq_search_batch for several pipeline shapes (sub-batch size x lanes), pageable and pinned
-caller buffers, 1 and 4 caller threads.  python tools/host_sweep.py [n] [nlist]"""
+caller buffers, 1 and 4 caller threads.  python tools/host_sweep.py [n] [nlist]
+HOST_SWEEP_BIG=1: calls of 8192 / 4096 queries against the number of lanes instead (round 3: no shape beats the default)."""
 import ctypes as C
 import os
 import sys
