@@ -213,3 +213,43 @@ def test_replicas_on_two_devices():
         b = two.debug_copy_index(name, np.empty(nbytes, np.uint8))
         assert np.array_equal(a, b), name
     one.close(); two.close()
+
+
+# ---- traffic counters: striped, and switchable -----------------------------------------------------------------------------
+def test_profile_counters_striped_and_switchable():
+    """The counters of an open profile live in 64 stripes (query index mod 64) summed by the host: the totals are what one set
+    of counters gave (compared with the oracle's probe sets, block bound off), whatever the batch size does to the stripes;
+    with the option profile_counters = 0 an open profile keeps its stage timings and counts nothing; results never change."""
+    data, built = build_index(n=12000, dim=128, nlist=48, total_bits=7, seed=341)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    sizes = built.list_sizes()
+    rng = np.random.default_rng(342)
+    q = np.ascontiguousarray(data[rng.choice(12000, 150, replace=False)] + 0.05 * rng.standard_normal((150, 128)).astype(np.float32))
+    idx.set_option("block_bound", 0)
+    want_blocks = want_vectors = 0
+    for i in range(q.shape[0]):
+        probes = oracle.select_probes(built, oracle.rotate(built, q[i]), 12)
+        want_blocks += int(((sizes[probes] + 31) // 32).sum())
+        want_vectors += int(sizes[probes].sum())
+    ref_ids = None
+    for nq_call in (150, 64, 7):  # (whole batch; one stripe round; ragged: stripes filled unevenly)
+        idx.profile_begin()
+        ids = []
+        for a0 in range(0, 150, nq_call):
+            ids.append(idx.batch_search_raw(q[a0:a0 + nq_call], rq.SearchParams(10, 12))[0])
+        idx.profile_end()
+        c = idx.profile_counters()
+        ids = np.concatenate(ids)
+        assert c["queries"] == 150 and c["vectors_probed"] == want_vectors and c["stream_entries"] == want_blocks == c["code_blocks"]
+        ref_ids = ids if ref_ids is None else ref_ids
+        assert np.array_equal(ids, ref_ids)
+    idx.set_option("profile_counters", 0)
+    idx.profile_begin()
+    ids = idx.batch_search_raw(q, rq.SearchParams(10, 12))[0]
+    idx.profile_end()
+    c = idx.profile_counters()
+    assert np.array_equal(ids, ref_ids) and c["queries"] == 0 and c["vectors_probed"] == 0 and c["code_blocks"] == 0
+    ms, launches = idx.profile_stage("scan")
+    assert launches >= 1 and ms > 0
+    idx.set_option("profile_counters", 1)
+    idx.close()
