@@ -270,6 +270,8 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *   "lazy_select" 0      score and stream every probed list (default 1: lists that are provably skipped as a whole —
  *                        every lower bound of the list at or above a select-time upper bound of the k-th distance — are
  *                        neither scored exactly nor streamed; their sizes still count in skipped_by_lower_bound)
+ *   "profile_counters" 0 an open profile (rbq_profile_begin) keeps its stage timings but not the traffic counters (default 1; the
+ *                        counters cost a pipelined caller 2-3 %: bench.py times without them and counts in a pass of its own)
  * and two that are not result-neutral:
  *   "rerank" 0/1         the optional full-precision rerank (needs rbq_index_set_rerank_vectors)
  *   "debug_replica" r    which replica rbq_debug_copy_index / rbq_debug_copy_workspace read */
