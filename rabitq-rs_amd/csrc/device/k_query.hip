@@ -98,12 +98,27 @@ hipError_t launch_select_rm(const SelectParams& p, const SelectGeom& g, size_t l
 }
 } // namespace
 
+// Static __shared__ of k_select_mfma<RM> (s_todo, s_zone, s_kept ...: 7424 B in the round-3 build), read once from the code
+// object: the dynamic-LDS decisions below must leave room for it (with the row in LDS and a 128 KB shortlist
+// window, dynamic alone reached 160 KB and the launch failed for n_lists in (6016, 7872] at D = 64).
+template <int RM>
+size_t select_static_lds() {
+    static const size_t v = [] {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_select_mfma<RM>)) != hipSuccess) { (void)hipGetLastError(); return (size_t)8192; }
+        return (size_t)fa.sharedSizeBytes;
+    }();
+    return v;
+}
+
 hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) {
     SelectGeom g;
     g.cap2 = next_pow2(2 * p.nprobe) < 64u ? 64u : next_pow2(2 * p.nprobe);
     const size_t lds0 = (size_t)g.cap2 * 8 + (size_t)p.D * 4 + kThreads * 4;
-    // <= 4096 lists: the score row lives in registers; else in LDS while it fits beside the shortlist window
-    g.row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536 && lds0 + (size_t)p.nlist * 4 <= kLdsPerWorkgroupMax) ? 1 : 0;
+    // <= 4096 lists: the score row lives in registers; else in LDS while it fits beside the shortlist window AND the
+    // kernel's static LDS
+    g.row_in_lds = (p.nlist > 4096 && (size_t)p.nlist * 4 <= 65536 &&
+                    lds0 + (size_t)p.nlist * 4 + select_static_lds<1>() <= kLdsPerWorkgroupMax) ? 1 : 0;
     size_t lds = lds0 + (g.row_in_lds ? (size_t)p.nlist * 4 : 0);
     g.stage = lds + (size_t)p.nprobe * 16 <= 48 * 1024 ? 1 : 0; // per-probe geometry staged in LDS
     if (g.stage) lds += (size_t)p.nprobe * 16;

@@ -107,12 +107,14 @@ struct Workspace {
     hipStream_t stream = nullptr;
     DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
+    PinBuf h_flag;           // rbq_search_batch: completion counter of the sub-batch in flight (added to by k_scan, polled by the host)
+    uint32_t flag_target = 0; // queries of that sub-batch (0: wait for the event instead)
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     void release() {
         for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
                           &heap_ws, &key_window})
             b->release();
-        h_in.release(); h_out.release();
+        h_in.release(); h_out.release(); h_flag.release();
         if (done) (void)hipEventDestroy(done);
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr; done = nullptr;
@@ -166,6 +168,8 @@ struct Replica {
     bool raw_borrowed = false;
     bool rerank = false;
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
+    bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
+    bool host_poll = true;      // rbq_search_batch: completion through a host-memory counter written by k_scan (no event wait)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
@@ -970,7 +974,7 @@ struct ProfScope {
 // k_scan launch shared by the IVF search and the MSTG posting-list scan
 int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, uint32_t top_k, uint64_t wl_stride,
                const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
-               rbq_diag* d_diag, bool mstg, const uint32_t* d_dead_skipped, hipStream_t stream) {
+               rbq_diag* d_diag, bool mstg, const uint32_t* d_dead_skipped, hipStream_t stream, unsigned int* done_ctr = nullptr) {
     ProfScope ps(ix, 3, stream, /*ext=*/true);
     ScanParams P;
     P.blocks = (const uint8_t*)ix->blocks.p; P.ids = (const uint64_t*)ix->ids.p; P.ex_codes = (const uint8_t*)ix->ex.p;
@@ -987,6 +991,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.mstg = mstg ? 1u : 0u;
     P.prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
+    P.done_ctr = done_ctr;
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
         int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);
@@ -1000,7 +1005,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
 // Core: everything on device pointers, enqueued on `stream`. Workspace buffers come from `w`.
 int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq, uint32_t top_k, uint32_t nprobe_in,
                   const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
-                  rbq_diag* d_diag, hipStream_t stream) {
+                  rbq_diag* d_diag, hipStream_t stream, unsigned int* done_ctr = nullptr) {
     const uint32_t D = ix->D, Dc = ix->Dc;
     const uint32_t nlist = (uint32_t)ix->n_lists;
     uint32_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
@@ -1008,7 +1013,9 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     // nprobe > kNprobeMax: the exact all-pairs ranking with its key window in global memory; top_k > kTopKMax: the heap in
     // global memory — both slow, both served (the reference clamps nprobe to n_lists and accepts any top_k)
     const bool big_nprobe = nprobe > kNprobeMax;
-    if (top_k > kTopKHardMax || (uint64_t)nq * ((uint64_t)top_k + 1) * 8 > (8ull << 30))
+    // the 8 GiB bound is the global-memory heap's (top_k beyond what the LDS holds); calls whose heap lives in LDS need no workspace
+    const bool heap_in_global = top_k > kTopKMax || scan_lds_bytes(Dc, D, ix->ex_bits, top_k) > kLdsPerWorkgroupMax;
+    if (top_k > kTopKHardMax || (heap_in_global && (uint64_t)nq * ((uint64_t)top_k + 1) * 8 > (8ull << 30)))
         return fail(RBQ_INVALID_CONFIG, "top_k too large for one call (top_k <= 2^20 and nq * top_k * 8 bytes of heap workspace <= 8 GiB)");
     if (ix->rerank && top_k > 1024) return fail(RBQ_INVALID_CONFIG, "rerank supports top_k <= 1024");
     const uint64_t wl_stride = std::max<uint64_t>(ix->nblk_desc_prefix[nprobe], 1);
@@ -1071,7 +1078,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
     if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
-                         /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
+                         /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream, done_ctr)))
         return rc;
     if (ix->rerank) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
         HIP_TRY(launch_rerank(d_queries, (uint32_t)nq, ix->dim, (const float*)ix->raw.p, ix->n_raw, ix->metric, top_k, d_ids, d_scores,
@@ -1126,6 +1133,14 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             out_pinned = false;
         }
     }
+    // page-locked queries are read by k_prep where they lie (device-side address of the caller's buffer)
+    const bool zero_copy = ix->host_zero_copy;
+    const float* c_queries = nullptr;
+    if (zero_copy && in_pinned && hipHostGetDevicePointer((void**)&c_queries, const_cast<float*>(queries), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        c_queries = nullptr;
+    }
+    const bool poll = ix->host_poll && !ix->rerank;
     tick(tp, t_attr);
     std::vector<Workspace*> lanes;
     struct Give { Replica* ix; std::vector<Workspace*>& l; bool drained = false;
@@ -1150,7 +1165,27 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     // hand the finished sub-batch j (in the lane's pinned buffer) to the caller's arrays
     auto deliver = [&](Workspace* w, uint64_t j) -> int {
         clk::time_point td = clk::now();
-        HIP_TRY(hipEventSynchronize(w->done));
+        if (w->flag_target) {
+            // every workgroup of k_scan adds 1 to the lane's counter (system-scope release) behind its results; the event is
+            // only consulted now and then, so that a failed launch cannot leave the caller spinning
+            volatile unsigned int* flag = (volatile unsigned int*)w->h_flag.p;
+            for (uint32_t spin = 0;; ++spin) {
+                if (__atomic_load_n((const unsigned int*)flag, __ATOMIC_ACQUIRE) >= w->flag_target) break;
+                if ((spin & 1023u) == 1023u) {
+                    const hipError_t e = hipEventQuery(w->done);
+                    if (e == hipSuccess) { // the kernel has ended: the counter is final
+                        if (__atomic_load_n((const unsigned int*)flag, __ATOMIC_ACQUIRE) >= w->flag_target) break;
+                        return fail(RBQ_DEVICE, "scan kernel ended without completing every query");
+                    }
+                    if (e != hipErrorNotReady) return fail(RBQ_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(e));
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        } else {
+            HIP_TRY(hipEventSynchronize(w->done));
+        }
         tick(td, t_wait);
         if (out_pinned) return RBQ_OK;
         const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
@@ -1168,10 +1203,19 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         if (j >= nlanes && (rc = deliver(w, j - nlanes))) return rc;
         const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
         const OutPack op(n, top_k, diag != nullptr);
-        if ((rc = w->queries.ensure(n * query_dim * 4))) return rc;
+        if (!zero_copy && (rc = w->queries.ensure(n * query_dim * 4))) return rc;
         const float* src = queries + q0 * query_dim;
         tp = clk::now();
-        if (in_pinned) {
+        const float* d_q = (const float*)w->queries.p; // where k_prep reads this sub-batch
+        if (c_queries) {
+            d_q = c_queries + q0 * query_dim;
+        } else if (zero_copy && !in_pinned) { // pageable: one host copy into the lane's pinned buffer, read from there
+            if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
+            std::memcpy(w->h_in.p, src, n * query_dim * 4);
+            float* hp = nullptr;
+            HIP_TRY(hipHostGetDevicePointer((void**)&hp, w->h_in.p, 0));
+            d_q = hp;
+        } else if (in_pinned) {
             HIP_TRY(hipMemcpyAsync(w->queries.p, src, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
         } else {
             if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
@@ -1198,8 +1242,15 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             k_ids = (uint64_t*)(dp + op.o_ids); k_scores = (float*)(dp + op.o_scores); k_counts = (uint32_t*)(dp + op.o_counts);
             k_diag = diag ? (rbq_diag*)(dp + op.o_diag) : nullptr;
         }
-        rc = search_device(ix, w, (const float*)w->queries.p, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag,
-                           w->stream);
+        unsigned int* d_flag = nullptr;
+        w->flag_target = 0;
+        if (poll) {
+            if ((rc = w->h_flag.ensure(64))) return rc;
+            __atomic_store_n((unsigned int*)w->h_flag.p, 0u, __ATOMIC_RELEASE); // (the lane's previous sub-batch has been delivered)
+            HIP_TRY(hipHostGetDevicePointer((void**)&d_flag, w->h_flag.p, 0));
+            w->flag_target = (uint32_t)n;
+        }
+        rc = search_device(ix, w, d_q, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag, w->stream, d_flag);
         if (rc) return rc;
         if (ix->rerank) {
             if ((rc = w->h_out.ensure(op.total))) return rc;
@@ -1409,36 +1460,54 @@ int rbq_search_batch(const rbq_index* ch, const float* queries, uint64_t nq, uin
             h->workers.back()->start();
         }
     }
-    std::vector<int> rcs(R, RBQ_OK);
-    std::vector<std::string> details(R);
-    struct Latch { std::mutex mu; std::condition_variable cv; size_t left; } latch;
-    latch.left = R - 1;
-    auto shard = [&](size_t r) {
+    // Everything the posted jobs touch lives in one shared state they hold by value: a job that is still running when this
+    // frame unwinds (post() threw after earlier replicas were posted) writes into memory it co-owns, never into a dead stack.
+    struct ShardState {
+        std::mutex mu; std::condition_variable cv; size_t left = 0;
+        std::vector<int> rcs; std::vector<std::string> details;
+    };
+    auto st = std::make_shared<ShardState>();
+    st->rcs.assign(R, RBQ_OK);
+    st->details.resize(R);
+    st->left = R - 1;
+    auto shard = [st, h, R, nq, queries, query_dim, top_k, nprobe, filter_words, filter_nbits, out_ids, out_scores, out_counts, diag](size_t r) {
         uint64_t q0, q1;
         rbq_host::shard_range(r, R, nq, &q0, &q1);
         try {
-            rcs[r] = search_host(h->reps[r], queries + q0 * query_dim, q1 - q0, query_dim, top_k, nprobe, filter_words, filter_nbits,
-                                 out_ids + q0 * top_k, out_scores + q0 * top_k, out_counts + q0, diag ? diag + q0 : nullptr);
-        } catch (...) { rcs[r] = RBQ_IO; g_err = "internal error"; }
-        details[r] = g_err; // thread-local in the worker
+            st->rcs[r] = search_host(h->reps[r], queries + q0 * query_dim, q1 - q0, query_dim, top_k, nprobe, filter_words, filter_nbits,
+                                     out_ids + q0 * top_k, out_scores + q0 * top_k, out_counts + q0, diag ? diag + q0 : nullptr);
+        } catch (...) { st->rcs[r] = RBQ_IO; g_err = "internal error"; }
+        st->details[r] = g_err; // thread-local in the worker
     };
-    for (size_t r = 1; r < R; ++r)
-        h->workers[r - 1]->post([&, r] {
-            shard(r);
-            std::lock_guard<std::mutex> lk(latch.mu);
-            if (--latch.left == 0) latch.cv.notify_one();
-        });
+    size_t posted = 0;
+    bool post_failed = false;
+    try {
+        for (size_t r = 1; r < R; ++r) {
+            h->workers[r - 1]->post([st, shard, r] {
+                shard(r);
+                std::lock_guard<std::mutex> lk(st->mu);
+                if (--st->left == 0) st->cv.notify_one();
+            });
+            ++posted;
+        }
+    } catch (...) { post_failed = true; }
+    if (post_failed) { // the caller's buffers must stay valid until the shards already under way have finished
+        std::unique_lock<std::mutex> lk(st->mu);
+        st->left -= (R - 1 - posted);
+        st->cv.wait(lk, [&] { return st->left == 0; });
+        return fail(RBQ_IO, "out of host memory");
+    }
     shard(0);
     {
         // the other shards finish about when this one does: poll briefly before blocking on the latch
         const auto t0 = std::chrono::steady_clock::now();
-        std::unique_lock<std::mutex> lk(latch.mu);
-        while (latch.left != 0) {
+        std::unique_lock<std::mutex> lk(st->mu);
+        while (st->left != 0) {
             if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
-            else latch.cv.wait(lk, [&] { return latch.left == 0; });
+            else st->cv.wait(lk, [&] { return st->left == 0; });
         }
     }
-    for (size_t r = 0; r < R; ++r) if (rcs[r]) return fail(rcs[r], details[r]);
+    for (size_t r = 0; r < R; ++r) if (st->rcs[r]) return fail(st->rcs[r], st->details[r]);
     return RBQ_OK;
     RBQ_GUARD_END
 }
@@ -1697,6 +1766,8 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_lanes")) ix->host_lanes = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_subbatch")) ix->host_subbatch = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
+        else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
+        else if (!std::strcmp(name, "host_poll")) ix->host_poll = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
             ix->rerank = value != 0;
