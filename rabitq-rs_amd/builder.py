@@ -31,6 +31,8 @@ def lib():
         L.rbq_built_lists.argtypes = [C.c_void_p]
         L.rbq_built_t_const.restype = C.c_float
         L.rbq_built_t_const.argtypes = [C.c_void_p]
+        L.rbq_built_list_recon.restype = C.c_int
+        L.rbq_built_list_recon.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float))]
         L.rbq_built_free.argtypes = [C.c_void_p]
         L.rbq_built_save_rbq1.restype = C.c_int
         L.rbq_built_save_rbq1.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)]
@@ -94,6 +96,25 @@ class BuiltIndex:
 
     def centroid(self, c):
         return np.ctypeslib.as_array(self.lists_ptr[c].centroid, shape=(self.padded_dim,)).copy()
+
+    def list_arrays(self, c):
+        """Every array of ClusterData c (src/ivf.rs:205-242) as numpy copies: centroid, ids, batch_data, ex_codes [n][D*ex/8],
+        f_add_ex, f_rescale_ex, delta, vl."""
+        lv = self.lists_ptr[c]
+        n, D, ex = int(lv.n), int(self.padded_dim), int(self.header.ex_bits)
+        exb = D * ex // 8
+        arr = lambda p, shape, dt: (np.ctypeslib.as_array(p, shape=shape).copy() if shape[0] else np.zeros(shape, dt))  # noqa: E731
+        d, v = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        assert lib().rbq_built_list_recon(self._h, c, C.byref(d), C.byref(v)) == RBQ_OK
+        return {"centroid": self.centroid(c), "ids": self.list_ids(c),
+                "batch_data": arr(lv.batch_data, (int(lv.batch_len),), np.uint8),
+                "ex_codes": arr(lv.ex_codes, (n, exb), np.uint8) if exb and n else np.zeros((n, exb), np.uint8),
+                "f_add_ex": arr(lv.f_add_ex, (n,), np.float32), "f_rescale_ex": arr(lv.f_rescale_ex, (n,), np.float32),
+                "delta": arr(d, (n,), np.float32), "vl": arr(v, (n,), np.float32)}
+
+    def rotator_blob(self):
+        h = self.header
+        return bytes(np.ctypeslib.as_array(h.rotator_blob, shape=(int(h.rotator_len),))) if h.rotator_len else b""
 
     def rotate(self, x):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -80,6 +80,8 @@ struct SelectParams {
     uint32_t top_k, ex_bits;
     int lazy;                     // 0: every probed list is scored and streamed (round-2 behaviour)
     int exact_members;            // diagnostics: dead_skipped and the probed-vector count must be exact
+    int tub_scale_log2;           // TEST ONLY (debug option lazy_tub_scale_log2, default 0): T_ub is multiplied by 2^this — a
+                                  // deliberately WRONG bound, so that the bound_violations audit can be shown to catch one
 };
 // key_window: null, or [nq][select_exact_np2(nprobe)] u64 in global memory (nprobe > kNprobeMax: the exact path with its key
 // window outside the LDS — slow, but every nprobe up to n_lists is served, as the reference does, src/ivf.rs:1791)

@@ -920,7 +920,9 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             for (uint32_t u = 0; u < nown && tid < n; ++u) {
                 const uint32_t k32 = (uint32_t)(keys[tid + u * kThreads] >> 32);
                 if (all || k32 <= tau_key) m_apx |= 1ull << u; // the approximate probe set (exactly nprobe lists unless keys tie at tau)
-                const bool cert = cost_of(k32) + 2.0f * eps < cost_bound;
+                // (2.01: the sum below is itself rounded in f32 — up to 2^-24 |cost|, the order of the 0.001 eps of headroom
+                // eps carries)
+                const bool cert = cost_of(k32) + 2.01f * eps < cost_bound;
                 if (cert) { m_certain |= 1ull << u; ++cnt; }
             }
             cnt = wave_sum_u32(cnt);
@@ -1007,7 +1009,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             auto head_info = [&](uint32_t r, float& g_add, float& g_err, uint32_t& gb, uint32_t& nvec) {
                 const uint64_t key = keys[s_head[r]];
                 const float ci = cost_of((uint32_t)(key >> 32));
-                g_add = ci + eps;
+                g_add = ci + 1.01f * eps; // (1.01: the rounding of this very sum)
                 if (metric == 0) g_err = sqrtf(fmaxf(g_add, 0.0f));
                 else g_err = sqrtf(fmaxf(qc.qnorm2 + s_hcn[r] + 2.0f * ci + 4.0f * eps, 0.0f)); // (as in the classification below)
                 gb = s_hgb[r]; nvec = s_hn[r];
@@ -1044,7 +1046,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 if (cum >= P.top_k) atomicMin(reinterpret_cast<int*>(&s_tub), total_key(myU));
             }
             __syncthreads();
-            const float T_ub = key_to_float((int32_t)s_tub);
+            const float T_ub = P.tub_scale_log2 ? ldexpf(key_to_float((int32_t)s_tub), P.tub_scale_log2) : key_to_float((int32_t)s_tub);
             const float cost_maxh = key_to_float((int32_t)s_maxh);
             lazy = T_ub < INFINITY;
             dbg_tub = __float_as_uint(T_ub);
@@ -1058,7 +1060,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                     const uint64_t key = keys[i];
                     const uint32_t cid = (uint32_t)key;
                     const float ci = cost_of((uint32_t)(key >> 32));
-                    const float clo = ci - eps, chi = ci + eps;
+                    const float clo = ci - 1.01f * eps, chi = ci + 1.01f * eps; // (1.01: the rounding of these sums)
                     float ge_lo, ge_hi;
                     if (metric == 0) { ge_lo = sqrtf(fmaxf(clo, 0.0f)); ge_hi = sqrtf(fmaxf(chi, 0.0f)); }
                     else { // canonical squared distance = |q|^2 + |c|^2 - 2 dot, within 4 eps of this evaluation (rank_mfma.hpp header)

@@ -107,14 +107,12 @@ struct Workspace {
     hipStream_t stream = nullptr;
     DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
-    PinBuf h_flag;           // rbq_search_batch: completion counter of the sub-batch in flight (added to by k_scan, polled by the host)
-    uint32_t flag_target = 0; // queries of that sub-batch (0: wait for the event instead)
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     void release() {
         for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
                           &heap_ws, &key_window})
             b->release();
-        h_in.release(); h_out.release(); h_flag.release();
+        h_in.release(); h_out.release();
         if (done) (void)hipEventDestroy(done);
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr; done = nullptr;
@@ -169,9 +167,9 @@ struct Replica {
     bool rerank = false;
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
-    bool host_poll = true;      // rbq_search_batch: completion through a host-memory counter written by k_scan (no event wait)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
+    int lazy_tub_scale_log2 = 0; // TEST ONLY: makes the select-time bound wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     bool profile_counters = true; // an open profile keeps the traffic counters (option profile_counters = 0: stage timings only —
                                   // the counters cost the pipelined run 2-3 %, bench.py collects them in a pass of their own)
@@ -974,7 +972,7 @@ struct ProfScope {
 // k_scan launch shared by the IVF search and the MSTG posting-list scan
 int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, uint32_t top_k, uint64_t wl_stride,
                const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
-               rbq_diag* d_diag, bool mstg, const uint32_t* d_dead_skipped, hipStream_t stream, unsigned int* done_ctr = nullptr) {
+               rbq_diag* d_diag, bool mstg, const uint32_t* d_dead_skipped, hipStream_t stream) {
     ProfScope ps(ix, 3, stream, /*ext=*/true);
     ScanParams P;
     P.blocks = (const uint8_t*)ix->blocks.p; P.ids = (const uint64_t*)ix->ids.p; P.ex_codes = (const uint8_t*)ix->ex.p;
@@ -991,7 +989,6 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.mstg = mstg ? 1u : 0u;
     P.prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
-    P.done_ctr = done_ctr;
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
         int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);
@@ -1005,7 +1002,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
 // Core: everything on device pointers, enqueued on `stream`. Workspace buffers come from `w`.
 int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq, uint32_t top_k, uint32_t nprobe_in,
                   const uint32_t* d_filter, uint64_t filter_nbits, uint64_t* d_ids, float* d_scores, uint32_t* d_counts,
-                  rbq_diag* d_diag, hipStream_t stream, unsigned int* done_ctr = nullptr) {
+                  rbq_diag* d_diag, hipStream_t stream) {
     const uint32_t D = ix->D, Dc = ix->Dc;
     const uint32_t nlist = (uint32_t)ix->n_lists;
     uint32_t nprobe = nprobe_in < 1 ? 1 : nprobe_in;
@@ -1065,6 +1062,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     // exists) and not when every probed block is to be streamed
     sp.lazy = (ix->lazy_select && !d_filter && !ix->no_block_bound) ? 1 : 0;
     sp.exact_members = d_diag ? 1 : 0;
+    sp.tub_scale_log2 = ix->lazy_tub_scale_log2;
     if (ix->exact_rank || big_nprobe) {
         uint64_t* kw = nullptr;
         if (big_nprobe) {
@@ -1078,7 +1076,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
     if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
-                         /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream, done_ctr)))
+                         /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
         return rc;
     if (ix->rerank) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
         HIP_TRY(launch_rerank(d_queries, (uint32_t)nq, ix->dim, (const float*)ix->raw.p, ix->n_raw, ix->metric, top_k, d_ids, d_scores,
@@ -1117,8 +1115,9 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     double t_attr = 0, t_ws = 0, t_stage = 0, t_enq = 0, t_wait = 0, t_out = 0;
     auto tick = [&](clk::time_point& t0, double& acc) { if (trace) { const auto t1 = clk::now(); acc += std::chrono::duration<double, std::micro>(t1 - t0).count(); t0 = t1; } };
     clk::time_point tp = clk::now();
-    const uint64_t SB = rbq_host::subbatch_size(nq, ix->host_subbatch); // 1024; a call below 2048 queries is cut in two
-    const uint64_t nsub = (nq + SB - 1) / SB;
+    // sub-batches shrink towards the end of the call (rbq_host_logic.hpp): the last one's kernel chain is what the caller waits for
+    const std::vector<std::pair<uint64_t, uint64_t>> plan = rbq_host::subbatch_plan(nq, ix->host_subbatch);
+    const uint64_t nsub = plan.size();
     const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 6u);
     const bool in_pinned = is_pinned_host_range(queries, nq * query_dim * 4);
     bool out_pinned = !ix->rerank && is_pinned_host_range(out_ids, nq * top_k * 8) && is_pinned_host_range(out_scores, nq * top_k * 4) &&
@@ -1134,13 +1133,14 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         }
     }
     // page-locked queries are read by k_prep where they lie (device-side address of the caller's buffer)
-    const bool zero_copy = ix->host_zero_copy;
+    // (measured, GIST-1M shape: 1024 queries per call 297 -> 280 us, 256: 212 -> 198 us; but one query 133 -> 147 us, and
+    // from 4096 queries per call the copy engine is faster than the waves' own PCIe reads: 678 -> 778 us — hence the window)
+    const bool zero_copy = ix->host_zero_copy && nq >= 32 && nq <= 2048;
     const float* c_queries = nullptr;
     if (zero_copy && in_pinned && hipHostGetDevicePointer((void**)&c_queries, const_cast<float*>(queries), 0) != hipSuccess) {
         (void)hipGetLastError();
         c_queries = nullptr;
     }
-    const bool poll = ix->host_poll && !ix->rerank;
     tick(tp, t_attr);
     std::vector<Workspace*> lanes;
     struct Give { Replica* ix; std::vector<Workspace*>& l; bool drained = false;
@@ -1165,30 +1165,10 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     // hand the finished sub-batch j (in the lane's pinned buffer) to the caller's arrays
     auto deliver = [&](Workspace* w, uint64_t j) -> int {
         clk::time_point td = clk::now();
-        if (w->flag_target) {
-            // every workgroup of k_scan adds 1 to the lane's counter (system-scope release) behind its results; the event is
-            // only consulted now and then, so that a failed launch cannot leave the caller spinning
-            volatile unsigned int* flag = (volatile unsigned int*)w->h_flag.p;
-            for (uint32_t spin = 0;; ++spin) {
-                if (__atomic_load_n((const unsigned int*)flag, __ATOMIC_ACQUIRE) >= w->flag_target) break;
-                if ((spin & 1023u) == 1023u) {
-                    const hipError_t e = hipEventQuery(w->done);
-                    if (e == hipSuccess) { // the kernel has ended: the counter is final
-                        if (__atomic_load_n((const unsigned int*)flag, __ATOMIC_ACQUIRE) >= w->flag_target) break;
-                        return fail(RBQ_DEVICE, "scan kernel ended without completing every query");
-                    }
-                    if (e != hipErrorNotReady) return fail(RBQ_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(e));
-                }
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
-            }
-        } else {
-            HIP_TRY(hipEventSynchronize(w->done));
-        }
+        HIP_TRY(hipEventSynchronize(w->done));
         tick(td, t_wait);
         if (out_pinned) return RBQ_OK;
-        const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
+        const uint64_t q0 = plan[j].first, n = plan[j].second;
         const OutPack op(n, top_k, diag != nullptr);
         const uint8_t* src = (const uint8_t*)w->h_out.p;
         std::memcpy(out_ids + q0 * top_k, src + op.o_ids, n * top_k * 8);
@@ -1201,7 +1181,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     for (uint64_t j = 0; j < nsub; ++j) {
         Workspace* w = lanes[j % nlanes];
         if (j >= nlanes && (rc = deliver(w, j - nlanes))) return rc;
-        const uint64_t q0 = j * SB, n = std::min(SB, nq - q0);
+        const uint64_t q0 = plan[j].first, n = plan[j].second;
         const OutPack op(n, top_k, diag != nullptr);
         if (!zero_copy && (rc = w->queries.ensure(n * query_dim * 4))) return rc;
         const float* src = queries + q0 * query_dim;
@@ -1242,15 +1222,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             k_ids = (uint64_t*)(dp + op.o_ids); k_scores = (float*)(dp + op.o_scores); k_counts = (uint32_t*)(dp + op.o_counts);
             k_diag = diag ? (rbq_diag*)(dp + op.o_diag) : nullptr;
         }
-        unsigned int* d_flag = nullptr;
-        w->flag_target = 0;
-        if (poll) {
-            if ((rc = w->h_flag.ensure(64))) return rc;
-            __atomic_store_n((unsigned int*)w->h_flag.p, 0u, __ATOMIC_RELEASE); // (the lane's previous sub-batch has been delivered)
-            HIP_TRY(hipHostGetDevicePointer((void**)&d_flag, w->h_flag.p, 0));
-            w->flag_target = (uint32_t)n;
-        }
-        rc = search_device(ix, w, d_q, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag, w->stream, d_flag);
+        rc = search_device(ix, w, d_q, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag, w->stream);
         if (rc) return rc;
         if (ix->rerank) {
             if ((rc = w->h_out.ensure(op.total))) return rc;
@@ -1264,7 +1236,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     give.drained = true; // every lane's last event has been waited for
     if (trace)
         std::fprintf(stderr, "[rbq host] nq=%llu sub=%llu lanes=%u pinned(in,out)=%d,%d us: attr %.1f ws %.1f stage %.1f enqueue %.1f wait %.1f copy-out %.1f\n",
-                     (unsigned long long)nq, (unsigned long long)SB, nlanes, (int)in_pinned, (int)out_pinned, t_attr, t_ws, t_stage, t_enq, t_wait, t_out);
+                     (unsigned long long)nq, (unsigned long long)plan[0].second, nlanes, (int)in_pinned, (int)out_pinned, t_attr, t_ws, t_stage, t_enq, t_wait, t_out);
     return RBQ_OK;
 }
 
@@ -1766,8 +1738,8 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_lanes")) ix->host_lanes = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_subbatch")) ix->host_subbatch = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
+        else if (!std::strcmp(name, "lazy_tub_scale_log2")) ix->lazy_tub_scale_log2 = value;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
-        else if (!std::strcmp(name, "host_poll")) ix->host_poll = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
             ix->rerank = value != 0;

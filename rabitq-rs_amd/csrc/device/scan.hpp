@@ -1520,15 +1520,6 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
             P.diag[(size_t)q * 3 + 2] = ex_bits ? n_ext : 0;
         }
     }
-    if (P.done_ctr) {
-        // Host-visible completion (rbq_search_batch): this query's ids / scores / count / diagnostics have been stored by
-        // several waves; each makes its stores visible at system scope, the barrier orders them before thread 0's add.  The
-        // host that reads nq from the counter (acquire) may read the results — it need not wait for the end-of-kernel
-        // signal and the wake-up behind it.
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(P.done_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 } // namespace rbq

@@ -492,6 +492,13 @@ int rbq_build_train_with_clusters(const float* data, uint64_t n, uint32_t dim,
 const rbq_header* rbq_built_header(const rbq_built* b) { return &b->hdr; }
 const rbq_list_view* rbq_built_lists(const rbq_built* b) { return b->views.data(); }
 float rbq_built_t_const(const rbq_built* b) { return b->t_const; }
+// ClusterData.delta / .vl of list c (reconstruction parameters: persisted by save_to_writer, src/ivf.rs:1455-1463, unused by
+// search and therefore not part of rbq_list_view)
+int rbq_built_list_recon(const rbq_built* b, uint64_t c, const float** delta, const float** vl) {
+    if (!b || c >= b->lists.size() || !delta || !vl) return RBQ_INVALID_CONFIG;
+    *delta = b->lists[c].delta.data(); *vl = b->lists[c].vl.data();
+    return RBQ_OK;
+}
 void rbq_built_free(rbq_built* b) { delete b; }
 
 // save_to_writer, src/ivf.rs:1317-1474. Caller frees *bytes with rbq_build_free_bytes.

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rbq.h"
@@ -160,11 +161,40 @@ struct OutPack {
 // replica r of R serves the contiguous query shard [q0, q1) of a batch of nq (batch_search is a par_iter over queries)
 inline void shard_range(uint64_t r, uint64_t R, uint64_t nq, uint64_t* q0, uint64_t* q1) { *q0 = r * nq / R; *q1 = (r + 1) * nq / R; }
 
-// sub-batch size of rbq_search_batch for a call (or replica shard) of nq queries: 1024 (also bounds the nq x nlist score
-// matrix per lane); fewer than 2048 queries are cut in two, so that the H2D copy and the kernels of the halves overlap
-inline uint64_t subbatch_size(uint64_t nq, uint64_t forced) {
-    uint64_t sb = forced ? forced : (nq >= 2048 ? 1024 : std::max<uint64_t>(256, (nq + 1) / 2));
-    return std::min<uint64_t>(sb, std::max<uint64_t>(nq, 1));
+// Sub-batches of one rbq_search_batch call (or replica shard) of nq queries, as (first query, count) in order.
+//   nq < 256            one sub-batch
+//   nq <= 2048          four sub-batches in the proportion 4:3:2:1 (multiples of 32 queries) over four lanes: the large ones
+//                       go first and run under the preparation of the later ones, the last one — whose kernel chain the caller
+//                       waits for — is small.  (Round 4, GIST-1M shape, page-locked buffers: 2048 queries per call 532 -> 462 us
+//                       against equal quarters, 562 against halves; 1024 per call: 296 either way — such a call is the time the
+//                       GPU needs for 1024 queries at its pipelined rate plus the latency of one four-kernel chain.)
+//   above               sub-batches of 1024 (which also bounds the nq x n_lists score matrix per lane); a tapered tail was
+//                       measured slower there (4096 per call: 828 against 688 us — the chip is saturated, smaller kernels only
+//                       add launches)
+// `forced` (diagnostic option host_subbatch) gives equal sub-batches of that size.
+inline std::vector<std::pair<uint64_t, uint64_t>> subbatch_plan(uint64_t nq, uint64_t forced) {
+    std::vector<std::pair<uint64_t, uint64_t>> plan;
+    if (nq == 0) return plan;
+    if (forced) {
+        for (uint64_t q0 = 0; q0 < nq; q0 += forced) plan.emplace_back(q0, std::min<uint64_t>(forced, nq - q0));
+        return plan;
+    }
+    auto taper = [&](uint64_t q0, uint64_t n, std::initializer_list<uint64_t> weights) {
+        uint64_t wsum = 0;
+        for (uint64_t w : weights) wsum += w;
+        uint64_t left = n, pos = q0;
+        size_t i = 0;
+        for (uint64_t w : weights) {
+            ++i;
+            uint64_t take = i == weights.size() ? left : std::min<uint64_t>(left, align_up((size_t)(n * w / wsum), 32));
+            if (take) plan.emplace_back(pos, take);
+            pos += take; left -= take;
+        }
+    };
+    if (nq < 256) { plan.emplace_back(0, nq); return plan; }
+    if (nq <= 2048) { taper(0, nq, {4, 3, 2, 1}); return plan; }
+    for (uint64_t q0 = 0; q0 < nq; q0 += 1024) plan.emplace_back(q0, std::min<uint64_t>(1024, nq - q0));
+    return plan;
 }
 
 } // namespace rbq_host

@@ -43,6 +43,11 @@ void rbq_hostcheck_outpack(uint64_t n, uint32_t top_k, int diag, uint64_t out[5]
     out[0] = op.o_ids; out[1] = op.o_scores; out[2] = op.o_counts; out[3] = op.o_diag; out[4] = op.total;
 }
 void rbq_hostcheck_shard(uint64_t r, uint64_t R, uint64_t nq, uint64_t out[2]) { rbq_host::shard_range(r, R, nq, &out[0], &out[1]); }
-uint64_t rbq_hostcheck_subbatch(uint64_t nq, uint64_t forced) { return rbq_host::subbatch_size(nq, forced); }
+// sub-batch plan of a call: writes at most cap (first, count) pairs, returns the number of sub-batches
+uint64_t rbq_hostcheck_plan(uint64_t nq, uint64_t forced, uint64_t* out, uint64_t cap) {
+    const auto plan = rbq_host::subbatch_plan(nq, forced);
+    for (size_t i = 0; i < plan.size() && i < cap; ++i) { out[2 * i] = plan[i].first; out[2 * i + 1] = plan[i].second; }
+    return plan.size();
+}
 
 } // extern "C"

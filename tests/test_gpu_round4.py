@@ -1,0 +1,300 @@
+"""GPU parity tests added in round 4 (VERDICT r3 items 2, 7, 10 and ADVICE r3): reference edge cases that had no GPU test —
+non-finite factors (src/ivf.rs:2031-2042, :2102-2104), NaN / Inf / all-zero / tiny / huge queries (total_cmp probe keys,
+:1808-1823) —, the seeded generator at data scales x1e-4, x1e4 and SIFT-like integer coordinates, duplicate-heavy indexes with
+in-distribution queries (so that the lazy probe selection really drops lists), every case with the lazy selection ON and
+OFF and with / without diagnostics; the `bound_violations` audit of the lazy selection; the host entry's zero-copy / polled
+paths; the independent RBQ1 writer; the select kernel's LDS budget.  Same bar as test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+import rabitq_rs_amd as rq
+from conftest import build_index, make_dataset
+from test_gpu_parity import _compare, _random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_lazy_on_off(built, idx, q, top_k, nprobe):
+    """_compare (oracle: ids, counts, scores, SearchDiagnostics; with and without diagnostics) under both selections; returns
+    the bound_violations audit of the lazy selection (see test_bound_violations_audit) and the lists dropped as a whole."""
+    idx.set_option("lazy_select", 1)
+    ids1, sc1, cnt1 = _compare(built, idx, q, top_k, nprobe)
+    _, _, _, d1 = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe), want_diag=True)
+    idx.set_option("lazy_select", 0)
+    ids0, sc0, cnt0 = _compare(built, idx, q, top_k, nprobe)
+    _, _, _, d0 = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe), want_diag=True)
+    idx.set_option("lazy_select", 1)
+    assert np.array_equal(ids0, ids1) and np.array_equal(cnt0, cnt1) and np.array_equal(sc0.view(np.uint32), sc1.view(np.uint32))
+    # a vector of a list declared dead that the reference would have evaluated shows up as one fewer skip / one more
+    # evaluation in the eager run: per query, the difference of the counters IS the number of violated bounds
+    viol = int(np.abs(d1.astype(np.int64) - d0.astype(np.int64)).sum())
+    return viol
+
+
+def _factor_view(built, c):
+    """writable views of list c's factor rows inside ClusterData.batch_data: (f_add, f_rescale, f_error)[block][32], and of
+    f_add_ex / f_rescale_ex"""
+    lv = built.lists_ptr[c]
+    D = built.padded_dim
+    stride = D * 4 + 384
+    nb = (int(lv.n) + 31) // 32
+    raw = np.ctypeslib.as_array(lv.batch_data, shape=(int(lv.batch_len),))
+    rows = raw.reshape(nb, stride)[:, D * 4:].view(np.float32).reshape(nb, 3, 32)
+    fa = np.ctypeslib.as_array(lv.f_add_ex, shape=(int(lv.n),))
+    fr = np.ctypeslib.as_array(lv.f_rescale_ex, shape=(int(lv.n),))
+    return rows, fa, fr
+
+
+NONFINITE = [np.inf, -np.inf, np.nan, -np.nan]
+
+
+@pytest.mark.parametrize("metric,bits", [(0, 7), (1, 7), (0, 3), (1, 3), (0, 1), (1, 1)])
+def test_non_finite_factors_follow_the_reference(metric, bits):
+    """+inf / -inf / NaN injected into f_add, f_rescale, f_error, f_add_ex, f_rescale_ex of a few vectors per list: the lower
+    bound falls back to 0 (L2) or -(dot_qc + |q|) (IP) (src/ivf.rs:2031-2042), a non-finite distance is dropped after it has
+    been counted as an extended evaluation (:2102-2104).  Oracle and GPU read the same mutated ClusterData."""
+    n, dim, nlist = 6000, 128, 24
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, normalize=(metric == 1), seed=4100 + bits + metric)
+    rng = np.random.default_rng(41)
+    touched = 0
+    for c in range(nlist):
+        rows, fa, fr = _factor_view(built, c)
+        nvec = int(built.lists_ptr[c].n)
+        if nvec == 0:
+            continue
+        for _ in range(6 if c % 3 else 2):  # (every third list stays almost clean: block bounds and whole-list bounds stay usable there)
+            v = int(rng.integers(0, nvec))
+            which = int(rng.integers(0, 5))
+            val = np.float32(NONFINITE[int(rng.integers(0, 4))])
+            if which < 3:
+                rows[v // 32, which, v % 32] = val
+            elif bits > 1:
+                (fa if which == 3 else fr)[v] = val
+            touched += 1
+    assert touched > 50
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q_far = make_dataset(24, dim, 6, 4242, normalize=(metric == 1))
+    q_near = data[rng.choice(n, 40, replace=False)] + 0.03 * rng.standard_normal((40, dim)).astype(np.float32)
+    for q in (q_far, q_near):
+        for top_k, nprobe in ((10, 8), (100, 24), (3, 1)):
+            assert _compare_lazy_on_off(built, idx, q.astype(np.float32), top_k, nprobe) == 0
+    idx.close()
+
+
+@pytest.mark.parametrize("metric,bits,rot,dim", [(0, 7, 1, 128), (1, 3, 1, 100), (0, 1, 0, 64), (1, 7, 1, 960)])
+def test_degenerate_queries(metric, bits, rot, dim):
+    """NaN, +-Inf, all-zero, 1e-30, 1e+30 and sign-mixed huge queries beside ordinary ones in one batch: the probe keys are
+    ordered by total_cmp (src/ivf.rs:1808-1823: NaN scores tie and fall back to the cluster id), non-finite lower bounds and
+    distances take the paths above, the approximate ranking's non-finite rows go through its canonical fallback."""
+    n, nlist = 5000, 20
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot, normalize=(metric == 1), seed=4200 + dim)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(42)
+    q = make_dataset(16, dim, 5, 77, normalize=(metric == 1))
+    q[1] = 0.0
+    q[2] = np.nan
+    q[3, 5] = np.nan
+    q[4] = np.inf
+    q[5, 7] = -np.inf
+    q[6] = 1e-30
+    q[7] = 1e30
+    q[8] = 1e30 * np.sign(rng.standard_normal(dim)).astype(np.float32)
+    q[9] = np.float32(3e38)
+    q[10] = np.float32(1e-45)   # subnormal
+    q[11] = -0.0
+    q[12, :] = 0.0
+    q[12, 0] = 1.0              # one-hot
+    for top_k, nprobe in ((10, 6), (1, 20), (100, 3)):
+        assert _compare_lazy_on_off(built, idx, q, top_k, nprobe) == 0
+    idx.close()
+
+
+def _scaled(seed, kind):
+    n, dim, nlist, bits, metric, rot, nq, top_k, nprobe = _random_case(seed)
+    rng = np.random.default_rng(seed + 77)
+    data = make_dataset(n, dim, max(nlist // 4, 1), seed, normalize=(metric == 1))
+    q_far = make_dataset(max(nq // 2, 1), dim, max(nlist // 4, 1), seed + 1000, normalize=(metric == 1))
+    q_near = data[rng.choice(n, nq - nq // 2 if nq > 1 else 1, replace=True)] + 0.05 * rng.standard_normal((nq - nq // 2 if nq > 1 else 1, dim)).astype(np.float32)
+    q = np.concatenate([q_far, q_near]).astype(np.float32)
+    if kind == "x1e-4":
+        data, q = data * np.float32(1e-4), q * np.float32(1e-4)
+    elif kind == "x1e4":
+        data, q = data * np.float32(1e4), q * np.float32(1e4)
+    elif kind == "int255":  # SIFT-like: integer-valued coordinates in [0, 255]
+        f = lambda a: np.clip(np.round(a * 40.0 + 128.0), 0, 255).astype(np.float32)  # noqa: E731
+        data, q = f(data), f(q)
+    return data.astype(np.float32), q, nlist, bits, metric, rot, top_k, nprobe
+
+
+@pytest.mark.parametrize("kind", ["x1e-4", "int255", "x1e4"])
+@pytest.mark.parametrize("seed", list(range(100, 160)))
+def test_random_configurations_at_other_scales(seed, kind):
+    """test_random_configurations_match_oracle's generator with the data (and queries) at scales x1e-4, x1e4 and as SIFT-like
+    integer coordinates; half of the queries are perturbed data points.  The slack terms of the lazy selection and of the
+    block bounds (kernels.hpp) are relative to |q|, |c|, delta: nothing in them may depend on O(1) data."""
+    data, q, nlist, bits, metric, rot, top_k, nprobe = _scaled(seed, kind)
+    _, built = build_index(nlist=nlist, total_bits=bits, metric=metric, rotator=rot, seed=seed, data=data, dim=data.shape[1])
+    idx = rq.IvfRabitqIndex.from_built(built)
+    assert _compare_lazy_on_off(built, idx, q, top_k, nprobe) == 0
+    idx.close()
+
+
+@pytest.mark.parametrize("kind,dim,bits,metric", [("x1", 128, 7, 0), ("int255", 128, 7, 0), ("x1e4", 960, 7, 0), ("x1e-4", 960, 3, 1),
+                                                  ("int255", 960, 7, 0), ("x1", 256, 1, 0)])
+def test_lazy_selection_drops_lists_at_every_scale(kind, dim, bits, metric):
+    """Larger indexes with in-distribution queries: the lazy selection must really drop lists here (dead_skipped > 0 for most
+    queries), and what it drops the reference skips vector by vector: bound_violations == 0."""
+    n, nlist, nq = 40000, 200, 96
+    rng = np.random.default_rng(4400 + dim)
+    data = make_dataset(n, dim, 50, 4400 + dim, normalize=(metric == 1))
+    q = data[rng.choice(n, nq, replace=False)] + 0.05 * rng.standard_normal((nq, dim)).astype(np.float32)
+    if kind == "x1e-4":
+        data, q = data * np.float32(1e-4), q * np.float32(1e-4)
+    elif kind == "x1e4":
+        data, q = data * np.float32(1e4), q * np.float32(1e4)
+    elif kind == "int255":
+        f = lambda a: np.clip(np.round(a * 40.0 + 128.0), 0, 255).astype(np.float32)  # noqa: E731
+        data, q = f(data), f(q)
+    _, built = build_index(nlist=nlist, total_bits=bits, metric=metric, seed=4400, data=data.astype(np.float32), dim=dim)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    for top_k, nprobe in ((10, 64), (100, 128)):
+        assert _compare_lazy_on_off(built, idx, q.astype(np.float32), top_k, nprobe) == 0
+    from test_gpu_round3 import _probe_taps
+    scanned, _, dead, _, _ = _probe_taps(idx, built, q.astype(np.float32), 10, 64, want_diag=True)
+    dropped = np.array([64 - len(s) for s in scanned])
+    assert (dropped > 0).mean() > 0.5 and dead.sum() > 0, (dropped.mean(), dead.sum())
+    idx.close()
+
+
+@pytest.mark.parametrize("metric,bits", [(0, 7), (1, 3), (0, 1)])
+def test_duplicate_heavy_index_with_lazy_selection(metric, bits):
+    """Few distinct vectors, each many times: bit-identical distances everywhere (exact-heap re-runs), lists of identical
+    summaries, ties in the select-time bound — with in-distribution queries, lazy selection on and off."""
+    rng = np.random.default_rng(45)
+    base = make_dataset(300, 64, 30, 45, normalize=(metric == 1))
+    reps = rng.integers(1, 60, 300)
+    data = np.repeat(base, reps, axis=0)
+    data = data[rng.permutation(len(data))]
+    _, built = build_index(nlist=40, total_bits=bits, metric=metric, seed=45, data=data, dim=64)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = np.concatenate([base[:40], base[40:80] + 0.01 * rng.standard_normal((40, 64)).astype(np.float32)]).astype(np.float32)
+    for top_k, nprobe in ((10, 16), (5, 40), (64, 24)):
+        assert _compare_lazy_on_off(built, idx, q, top_k, nprobe) == 0
+    assert idx.heap_restarts() > 0
+    idx.close()
+
+
+def test_bound_violations_audit_detects_a_loosened_bound():
+    """The audit itself: with the select-time bound deliberately made WRONG (debug option lazy_tub_scale: T_ub multiplied by
+    1/64 — lists are then declared dead against a threshold far below the true k-th distance) the counters of the lazy and
+    the eager run must differ: bound_violations > 0, and the results change.  With the option back at 1 the same data gives 0."""
+    n, dim, nlist = 30000, 128, 128
+    rng = np.random.default_rng(46)
+    data = make_dataset(n, dim, 32, 46)
+    _, built = build_index(nlist=nlist, total_bits=7, seed=46, data=data, dim=dim)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = (data[rng.choice(n, 64, replace=False)] + 0.05 * rng.standard_normal((64, dim)).astype(np.float32)).astype(np.float32)
+    sp = rq.SearchParams(10, 48)
+    idx.set_option("lazy_select", 0)
+    ids0, _, _, d0 = idx.batch_search_raw(q, sp, want_diag=True)
+    idx.set_option("lazy_select", 1)
+    ids1, _, _, d1 = idx.batch_search_raw(q, sp, want_diag=True)
+    assert np.array_equal(d0, d1) and np.array_equal(ids0, ids1)
+    idx.set_option("lazy_tub_scale_log2", -6)
+    ids2, _, _, d2 = idx.batch_search_raw(q, sp, want_diag=True)
+    viol = int(np.abs(d2.astype(np.int64) - d0.astype(np.int64)).sum())
+    assert viol > 0, "a bound 64 x too tight must be caught by the audit"
+    idx.set_option("lazy_tub_scale_log2", 0)
+    ids3, _, _, d3 = idx.batch_search_raw(q, sp, want_diag=True)
+    assert np.array_equal(d0, d3) and np.array_equal(ids0, ids3)
+    idx.close()
+
+
+@pytest.mark.parametrize("zero_copy", [0, 1])
+def test_host_entry_paths_give_identical_results(zero_copy):
+    """rbq_search_batch with the round-4 host path (queries read from page-locked memory in place, tapered sub-batches):
+    pageable and page-locked buffers, ragged call sizes
+    around every boundary of the sub-batch plan, with diagnostics and a filter — always the device entry's bits."""
+    import torch
+    data, built = build_index(n=20000, dim=128, nlist=96, total_bits=7, seed=471)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    idx.set_option("host_zero_copy", zero_copy)
+    lib = rq.index.lib()
+    dev = torch.device("cuda", 0)
+    top_k, nprobe = 10, 12
+    allowed = np.arange(0, 20000, 3)
+    words = np.zeros((20000 + 31) // 32, np.uint32)
+    np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+    for nq in (1, 31, 32, 33, 255, 256, 257, 1000, 2048, 2049, 2600):
+        q = make_dataset(nq, 128, 24, 4700 + nq)
+        qd = torch.from_numpy(q).to(dev)
+        d_i = torch.empty(nq, top_k, dtype=torch.int64, device=dev)
+        d_s = torch.empty(nq, top_k, dtype=torch.float32, device=dev)
+        d_c = torch.empty(nq, dtype=torch.int32, device=dev)
+        idx.search_batch_device(qd.data_ptr(), nq, 128, top_k, nprobe, d_i.data_ptr(), d_s.data_ptr(), d_c.data_ptr(), stream=None)
+        torch.cuda.synchronize(dev)
+        want = (d_i.cpu().numpy().view(np.uint64), d_s.cpu().numpy().view(np.uint32), d_c.cpu().numpy().view(np.uint32))
+        ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe), want_diag=(nq % 2 == 1))
+        assert np.array_equal(ids, want[0]) and np.array_equal(sc.view(np.uint32), want[1]) and np.array_equal(cnt, want[2]), nq
+        nb = [nq * 128 * 4, nq * top_k * 8, nq * top_k * 4, nq * 4]
+        ptrs = [lib.rbq_host_alloc(b) for b in nb]
+        C.memmove(ptrs[0], q.ctypes.data, nb[0])
+        for rep in range(2):  # (the lanes are reused by the second call)
+            C.memset(ptrs[1], 0xAB, nb[1])
+            rc = lib.rbq_search_batch(idx._h, ptrs[0], nq, 128, top_k, nprobe, None, 0, ptrs[1], ptrs[2], ptrs[3], None)
+            assert rc == 0
+            pid = np.ctypeslib.as_array(C.cast(ptrs[1], C.POINTER(C.c_uint64)), shape=(nq, top_k))
+            psc = np.ctypeslib.as_array(C.cast(ptrs[2], C.POINTER(C.c_uint32)), shape=(nq, top_k))
+            pct = np.ctypeslib.as_array(C.cast(ptrs[3], C.POINTER(C.c_uint32)), shape=(nq,))
+            assert np.array_equal(pid, want[0]) and np.array_equal(psc, want[1]) and np.array_equal(pct, want[2]), (nq, rep)
+        for p in ptrs:
+            lib.rbq_host_free(p)
+        if nq in (33, 1000):
+            rc, oids, _, ocnt, _ = oracle.search_batch(built, q, top_k, nprobe, words, 20000)
+            fid, _, fct, _ = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe), words, 20000)
+            assert np.array_equal(fid, oids) and np.array_equal(fct, ocnt)
+    idx.close()
+
+
+def test_independent_rbq1_writer_loads_to_identical_device_arrays():
+    """tests/rbq1_writer.py (pure Python, written from src/ivf.rs:1317-1474 alone): its stream loads through
+    rbq_index_load_rbq1 to the SAME device arrays as rbq_index_create over the builder's ClusterData, and searches identically."""
+    from rbq1_writer import from_built
+    for bits, metric, rot, dim in ((7, 0, 1, 100), (3, 1, 0, 48), (1, 0, 1, 64)):
+        data, built = build_index(n=3000, dim=dim, nlist=20, total_bits=bits, metric=metric, rotator=rot, normalize=(metric == 1), seed=480 + bits)
+        blob = from_built(built)
+        a = rq.IvfRabitqIndex.from_built(built)
+        b = rq.IvfRabitqIndex.load_from_bytes(blob)
+        ln = a.debug_copy_index("list_n", np.empty(20, np.uint32))
+        assert np.array_equal(ln, b.debug_copy_index("list_n", np.empty(20, np.uint32)))
+        nslots = int(((ln + 31) // 32).sum()) * 32
+        D = built.padded_dim
+        Dc = (D + 63) // 64 * 64
+        sizes = {"blocks": nslots // 32 * (4 * Dc + 384), "ids": nslots * 8, "bsum": nslots, "centroids": 20 * D * 4, "list_gb0": 20 * 4}
+        if bits > 1:
+            sizes["fadd_ex"] = nslots * 4
+            sizes["fres_ex"] = nslots * 4
+        for name, nb in sizes.items():
+            assert np.array_equal(a.debug_copy_index(name, np.empty(nb, np.uint8)), b.debug_copy_index(name, np.empty(nb, np.uint8))), name
+        q = make_dataset(40, dim, 5, 481, normalize=(metric == 1))
+        _compare(built, b, q, 10, 6)
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("nlist,nprobe,dim", [(7000, 5000, 64), (6100, 4097, 64), (7800, 8000, 64)])
+def test_select_lds_budget_with_static_lds(nlist, nprobe, dim):
+    """n_lists in (6016, 7872] with nprobe in 4097..8192 at D = 64 put the score row in LDS beside a 128 KB shortlist
+    window; with the kernel's static LDS (7.4 KB) the workgroup exceeded the 160 KB of a CU and the call returned RBQ_DEVICE."""
+    n = nlist * 3
+    rng = np.random.default_rng(49)
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    cent = data[:nlist].copy()
+    assign = (np.arange(n) % nlist).astype(np.uint32)
+    built = rq.builder.train_with_clusters(data, cent, assign, 3, 0, rq.RotatorType.FhtKacRotator, 49, True)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = rng.standard_normal((6, dim)).astype(np.float32)
+    _compare(built, idx, q, 10, nprobe)
+    idx.close()

@@ -50,8 +50,8 @@ L.rbq_hostcheck_crc32.restype = C.c_uint32
 L.rbq_hostcheck_crc32.argtypes = [C.c_void_p, C.c_size_t]
 L.rbq_hostcheck_outpack.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]
 L.rbq_hostcheck_shard.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
-L.rbq_hostcheck_subbatch.restype = C.c_uint64
-L.rbq_hostcheck_subbatch.argtypes = [C.c_uint64, C.c_uint64]
+L.rbq_hostcheck_plan.restype = C.c_uint64
+L.rbq_hostcheck_plan.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64]
 
 def parse(blob):
     buf = (C.c_uint8 * len(blob)).from_buffer_copy(bytes(blob))   # exact-size heap copy: a read past the end is an ASan report
@@ -106,9 +106,23 @@ for R in (1, 2, 3, 8, 16):
             assert s[0] == prev and s[1] >= s[0]
             prev = s[1]
         assert prev == nq
-for nq in (1, 2, 255, 256, 512, 1023, 1024, 2047, 2048, 100000):
-    sb = L.rbq_hostcheck_subbatch(nq, 0)
-    assert 1 <= sb <= max(nq, 1) and sb <= 1024 and (nq < 2048 or sb == 1024)
+pl = (C.c_uint64 * 4096)()
+for forced in (0, 100, 1024):
+    for nq in (1, 2, 31, 255, 256, 257, 300, 512, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 2600, 3583, 3584, 3585, 4096, 100000):
+        m = L.rbq_hostcheck_plan(nq, forced, pl, 2048)
+        assert 1 <= m <= 2048, (nq, forced, m)
+        pos = 0
+        sizes = []
+        for i in range(m):
+            assert pl[2 * i] == pos and pl[2 * i + 1] >= 1
+            pos += pl[2 * i + 1]
+            sizes.append(pl[2 * i + 1])
+        assert pos == nq and max(sizes) <= max(1024, forced), (nq, forced, sizes)
+        if not forced:
+            assert sizes == sorted(sizes, reverse=True) and (nq < 256 or m >= 3 or nq > 2048), (nq, sizes)
+            if 256 <= nq <= 2048:
+                assert sizes[-1] <= nq // 4 and sizes[0] >= nq // 3, (nq, sizes)
+assert L.rbq_hostcheck_plan(0, 0, pl, 2048) == 0
 print("outcomes", len(outcomes), sum(outcomes.values()))
 for k, v in sorted(outcomes.items(), key=lambda kv: -kv[1])[:8]:
     print("  %%5d rc=%%d %%s" %% (v, k[0], k[1]))

@@ -1,5 +1,5 @@
 """Per-call time of rbq_search_batch (host buffers in and out, ONE caller thread) against the host-path switches:
-zero-copy query reads, polled completion, sub-batch size x lanes.  Median / p10 of many calls (the box's host CPUs are shared:
+zero-copy query reads, sub-batch size x lanes.  Median / p10 of many calls (the box's host CPUs are shared:
 single regions scatter), ids checked against the device entry.
 python tools/host_call_probe.py [n] [nlist]        HOST_PROBE_SHAPES="256x4,512x2" HOST_PROBE_NQ="1024,4096"
 """
@@ -76,9 +76,8 @@ def run(batch, shapes, reps):
 
     print(f"--- {batch} queries per call, {reps} calls per cell; us per call: median (p10) -> M queries/s at the median", flush=True)
     for zc in (0, 1):
-        for poll in (0, 1):
+        for poll in (0,):
             idx.set_option("host_zero_copy", zc)
-            idx.set_option("host_poll", poll)
             for sub, lanes in shapes:
                 idx.set_option("host_subbatch", sub)
                 idx.set_option("host_lanes", lanes)
@@ -98,8 +97,8 @@ def shapes_of(env, default):
 
 for nq_ in [int(t) for t in os.environ.get("HOST_PROBE_NQ", "1024,4096,256,64,1").split(",")]:
     if nq_ >= 4096:
-        run(nq_, shapes_of("HOST_PROBE_SHAPES_BIG", [(1024, 4), (512, 8), (256, 8), (0, 0)]), 150)
+        run(nq_, shapes_of("HOST_PROBE_SHAPES_BIG", [(1024, 4), (0, 0)]), 150)
     elif nq_ >= 1024:
-        run(nq_, shapes_of("HOST_PROBE_SHAPES", [(512, 2), (256, 4), (128, 8), (0, 0)]), 300)
+        run(nq_, shapes_of("HOST_PROBE_SHAPES", [(512, 2), (256, 4), (0, 0)]), 300)
     else:
         run(nq_, [(0, 0)], 300)
