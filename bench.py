@@ -26,8 +26,13 @@ Prints one JSON line (rank 0).  What the objects mean:
                         launch time — a true HBM-roofline position (<= 1)
   pruned                the product configuration (bound ON) of the timed region: bytes the kernel actually requested,
                         counted inside the kernel in the same launches, block skip fraction, frac = requested/time/peak
-  pcie_inclusive        rbq_search_batch (host buffers in, host buffers out: what a Rust caller binds), 1 and 4 caller
-                        threads, pageable and page-locked buffers
+  host_call             THE CALL THE REFERENCE BINDS: one rbq_search_batch call per step from one caller thread (host buffers in and
+                        out, distinct batches), median call — what a Rust / Python caller of the drop-in sees; `value` stays the
+                        device-resident rate (bench contract: inputs in HBM when the timed region starts)
+  pcie_inclusive        the same entry point with 1 and 4 caller threads, pageable and page-locked buffers, 1 and 4 batches per call
+  regime                what bounds the timed (pruned) configuration: every stage's duration under overlap, resident waves x time per
+                        query against the chip's wave slots
+  sensitivity           lists scanned / queries/s / recall against the intrinsic dimension of the data (16 ... 128, isotropic)
   datasets              the low-intrinsic-dimension mixture (headline) and SURVEY 8d's isotropic mixture, each with recall,
                         rate and skip fraction
   cpu_baseline          the oracle (C restatement of the reference's AVX2/AVX-512 FastScan path) on the host cores: median
@@ -86,7 +91,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ab", action="store_true", help="kernel A/B runs: only the per-stage pass of the supplementary legs")
     ap.add_argument("--no-extras", action="store_true", help="skip the supplementary legs (second data set, host API, per-stage pass)")
-    ap.add_argument("--dataset", default="mixture_id32", choices=["mixture_id32", "isotropic"],
+    ap.add_argument("--dataset", default="mixture_id32", choices=["mixture_id16", "mixture_id32", "mixture_id64", "mixture_id128", "isotropic"],
                     help="headline data: low-intrinsic-dimension mixture (default) or SURVEY 8d's isotropic mixture")
     ap.add_argument("--device-build", action="store_true",
                     help="build the index with the GPU-side encoder only (large n: no CPU build, no oracle check)")
@@ -129,10 +134,12 @@ class Mixture:
     def __init__(self, torch, dev, dim, nlist, kind, normalize):
         self.torch, self.dev, self.dim, self.kind, self.normalize = torch, dev, dim, kind, normalize
         self.kgen = max(nlist // 4, 1)
+        # "mixture_idN": intrinsic dimension N (the headline is N = 32; the sensitivity leg sweeps it)
+        self.idim = int(kind[len("mixture_id"):]) if kind.startswith("mixture_id") else INTRINSIC_DIM
         gm = torch.Generator(device=dev)
         gm.manual_seed(20260101)
         self.means = torch.randn(self.kgen, dim, generator=gm, device=dev)
-        self.A = torch.randn(INTRINSIC_DIM, dim, generator=gm, device=dev) / (INTRINSIC_DIM ** 0.5)
+        self.A = torch.randn(self.idim, dim, generator=gm, device=dev) / (self.idim ** 0.5)
 
     def draw(self, n, seed):
         torch, dev = self.torch, self.dev
@@ -145,7 +152,7 @@ class Mixture:
             if self.kind == "isotropic":
                 x[s:e] = self.means[comp[s:e]] + 0.35 * torch.randn(e - s, self.dim, generator=g, device=dev)
             else:
-                z = torch.randn(e - s, INTRINSIC_DIM, generator=g, device=dev)
+                z = torch.randn(e - s, self.idim, generator=g, device=dev)
                 x[s:e] = self.means[comp[s:e]] + 0.35 * (z @ self.A) + 0.1 * torch.randn(e - s, self.dim, generator=g, device=dev)
         if self.normalize:
             x /= x.norm(dim=1, keepdim=True)
@@ -474,11 +481,12 @@ def main():
         with the counters ON, untimed: the counts are deterministic per batch.  The stage timings (HIP events riding on the
         dispatch packets, free) come from the timed launches."""
         dts, own, prof = run_timed(index, qb, nprobe, steps, warmup, ns, gather, min_seconds, counters=False)
-        _, _, pc = run_timed(index, qb, nprobe, int(qb.shape[0]), 0, ns, False, 0.0, counters=True)
+        _, _, pc = run_timed(index, qb, nprobe, int(qb.shape[0]), 0, ns, False, 0.0, counters=True, stages=("prep", "rank", "select", "scan"))
         prof["counters"], prof["algorithmic_bytes"], prof["counter_steps"] = pc["counters"], pc["algorithmic_bytes"], pc["steps_total"]
+        prof["stage_ms_overlapped"] = pc["stage_ms"]  # every stage's mean duration while the batches overlap on ns streams
         return dts, own, prof
 
-    def run_timed(index, qb, nprobe, steps, warmup, ns, gather, min_seconds=0.0, counters=True):
+    def run_timed(index, qb, nprobe, steps, warmup, ns, gather, min_seconds=0.0, counters=True, stages=("scan",)):
         """Timed regions of exactly `steps` steps each (after `warmup` untimed steps), batches qb[NB'] rotating, on ns streams.
         Every region is bracketed by barrier + synchronize on both sides; regions repeat until `min_seconds` have been
         measured (a 20-step region lasts 4 ms: one sample of it is mostly noise).  Returns (region seconds — max over ranks —,
@@ -539,7 +547,7 @@ def main():
         # counters run on every launch (one atomicAdd per workgroup at exit).
         index.set_option("profile_counters", 1 if counters else 0)
         if True:
-            index.profile_begin(stages=("scan",), every=int(os.environ.get("RBQ_BENCH_TAP_EVERY", str(max(1, steps // 25)))))
+            index.profile_begin(stages=stages, every=int(os.environ.get("RBQ_BENCH_TAP_EVERY", str(max(1, steps // 25)))))
         dts, own, t_issue = [], [], 0.0
         while True:
             t0 = time.perf_counter()
@@ -562,7 +570,8 @@ def main():
         ms, launches = index.profile_stage("scan")
         prof = {"issue_s": t_issue / nreg, "scan_ms": ms, "scan_launches": launches, "scan_samples_ms": [round(float(v), 4) for v in index.profile_stage_samples("scan")][:64],
                 "counters": index.profile_counters(), "steps_total": steps * nreg, "counter_steps": steps * nreg,
-                "algorithmic_bytes": index.profile_scan_bytes()}
+                "algorithmic_bytes": index.profile_scan_bytes(),
+                "stage_ms": {st_: index.profile_stage(st_)[0] for st_ in stages}}
         for st in streams:
             index.release_stream(st.cuda_stream)
         return dts, own, prof
@@ -581,6 +590,22 @@ def main():
             out.append(d_ids.cpu().numpy().view(np.uint64).copy())
         index.release_stream(st.cuda_stream)
         return np.stack(out)
+
+    def lists_scanned(index, qbatch):
+        """mean number of probed lists that reach k_scan (the others are provably skipped as a whole by the lazy selection)"""
+        st = torch.cuda.Stream(dev)
+        d_i = torch.empty(a.batch, a.top_k, dtype=torch.int64, device=dev)
+        d_s = torch.empty(a.batch, a.top_k, dtype=torch.float32, device=dev)
+        d_c = torch.empty(a.batch, dtype=torch.int32, device=dev)
+        index.search_batch_device(qbatch.data_ptr(), a.batch, a.dim, a.top_k, a.nprobe, d_i.data_ptr(), d_s.data_ptr(), d_c.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+        try:
+            ds = index.debug_copy_workspace(st.cuda_stream, "dead_skipped", np.empty((2, a.batch), np.uint32))
+            out_ = float(ds[1].mean())
+        except Exception:  # noqa: BLE001
+            out_ = None
+        index.release_stream(st.cuda_stream)
+        return out_
 
     def pruned_object(prof, steps):
         c = prof["counters"]
@@ -786,6 +811,7 @@ def main():
     # the host-buffer entry point (rbq_search_batch: H2D of the queries, the four kernels, D2H of the results) — what a
     # CPU-side caller such as the Rust shim binds (src/ivf.rs:1743-1752)
     pcie = None
+    host_call = None
     if extras:
         import ctypes as C
         import threading
@@ -828,11 +854,35 @@ def main():
                     rc = lib.rbq_search_batch(idx._h, p[0], per_call, a.dim, a.top_k, a.nprobe, None, 0, p[1], p[2], p[3], None)
                     assert rc == 0
 
+            def per_call_times(fn, ncalls):
+                """ONE caller thread, one call at a time: seconds of each of `ncalls` calls (distinct query sets in rotation)"""
+                ts = np.empty(ncalls)
+                for r in range(ncalls):
+                    t0 = time.perf_counter()
+                    fn(r)
+                    ts[r] = time.perf_counter() - t0
+                return ts
+
+            def one_pageable(r):
+                idx.batch_search_raw(qh[r % nsets], sp)
+
+            def one_pinned(r):
+                p = pin[0][r % nsets]
+                assert lib.rbq_search_batch(idx._h, p[0], per_call, a.dim, a.top_k, a.nprobe, None, 0, p[1], p[2], p[3], None) == 0
+
             timed(pageable, 1, 3, 1)
             timed(pinned, 1, 3, 1)
             reps = max(10, 64 * a.batch // per_call)  # calls per thread and try (a few tens of ms: thread start-up does not weigh)
             want = ids_all[:kb].reshape(per_call, a.top_k)
+            ncalls = max(40, 200 * a.batch // per_call)
+            tp_, tg_ = per_call_times(one_pinned, ncalls), per_call_times(one_pageable, ncalls)
             leg = {"queries_per_call": per_call,
+                   # the robust single-caller figures: MEDIAN call (the box shares its host CPUs; best-of-N flatters)
+                   "calls_timed": ncalls,
+                   "page_locked_us_per_call": {"median": float(np.median(tp_) * 1e6), "p10": float(np.percentile(tp_, 10) * 1e6), "p90": float(np.percentile(tp_, 90) * 1e6)},
+                   "pageable_us_per_call": {"median": float(np.median(tg_) * 1e6), "p10": float(np.percentile(tg_, 10) * 1e6), "p90": float(np.percentile(tg_, 90) * 1e6)},
+                   "page_locked_queries_per_s": per_call / float(np.median(tp_)),
+                   "pageable_queries_per_s": per_call / float(np.median(tg_)),
                    "queries_per_s_1_caller_thread": timed(pageable, 1, reps),
                    f"queries_per_s_{nthr}_caller_threads": timed(pageable, nthr, reps),
                    "pinned_queries_per_s_1_caller_thread": timed(pinned, 1, reps),
@@ -852,6 +902,27 @@ def main():
         pcie = {"per_call_1x_batch": host_leg(a.batch)}
         if NB >= 8:
             pcie["per_call_4x_batch"] = host_leg(4 * a.batch)
+        # The call the reference binds, first-class: batch_search(&[&[f32]], params) (src/ivf.rs:1743-1752) = ONE rbq_search_batch
+        # call per step from ONE caller thread, host slices in, host vectors out, distinct batches.  `value` stays the
+        # device-resident rate (the bench contract: inputs resident in HBM when the timed region starts); this object is what a
+        # Rust / Python caller of the drop-in sees.
+        l1 = pcie["per_call_1x_batch"]
+        host_call = {"what": "rbq_search_batch: host buffers in and out, ONE caller thread, ONE call per step, distinct batches; median call of "
+                             f"{l1['calls_timed']} (the reference's batch_search binding, src/ivf.rs:1743-1752)",
+                     "queries_per_call": a.batch,
+                     "queries_per_s": l1["page_locked_queries_per_s"], "buffers": "page-locked (rbq_host_alloc)",
+                     "us_per_call": l1["page_locked_us_per_call"],
+                     "pageable_queries_per_s": l1["pageable_queries_per_s"], "pageable_us_per_call": l1["pageable_us_per_call"],
+                     "over_device_resident": l1["page_locked_queries_per_s"] / (value / world),
+                     "ids_identical_to_device_path": l1["pinned_ids_identical"] and l1["ids_identical_to_device_path"],
+                     "bound": "one call = the time the GPU needs for `queries_per_call` queries at its pipelined rate (1 / device-resident rate) "
+                              "+ the latency of ONE four-kernel chain (latency.p50 of a small call): the sub-batches of a call overlap like the "
+                              "device-resident batches do, but nothing overlaps the first chain's fill and the last chain's drain",
+                     "model_us_per_call": None}
+        if "per_call_4x_batch" in pcie:
+            l4 = pcie["per_call_4x_batch"]
+            host_call["per_call_4x_batch"] = {"queries_per_call": l4["queries_per_call"], "queries_per_s": l4["page_locked_queries_per_s"],
+                                              "pageable_queries_per_s": l4["pageable_queries_per_s"], "us_per_call": l4["page_locked_us_per_call"]}
         pcie["note"] = ("rbq_search_batch, host buffers in and out, distinct batches per call, best of 3 runs per figure; default rows = pageable numpy buffers "
                         "(staged through the handle's pinned memory), pinned_* rows = caller buffers from rbq_host_alloc (DMA-ed / "
                         "written directly).  One call of one batch is bound by the serial latency of its four kernels + the H2D copy; "
@@ -860,6 +931,8 @@ def main():
                         "caller sees.")
 
     latency = latency_leg() if (extras and not a.no_latency) else None
+    if host_call is not None and latency is not None and "64" in latency:
+        host_call["model_us_per_call"] = a.batch / (value / world) * 1e6 + latency["64"]["p50_us"]
 
     # Self-check for indexes no CPU oracle run can cover (device-built: cfg5 at 100 M vectors): the first 256 queries again
     # with every shortcut switched off — canonical all-pairs ranking instead of the MFMA shortlist, BinaryHeap emulation from
@@ -921,6 +994,91 @@ def main():
                                          "reference's estimator itself cannot separate them (DESIGN.md)"}
         idx2.close()
 
+    # What bounds the TIMED configuration.  It is not HBM (97 % of the probed blocks are provably pruned: `pruned`) and not issue
+    # slots: every kernel of the path is a chain of dependent phases per query, so the chip fills with resident waves that
+    # wait.  Per stage: the kernel instantiation this call shape launches and what it occupies (rbq_debug_stage_resources: live,
+    # from the code object), its duration alone and under overlap (HIP events on the dispatch packets); resident wave-time per
+    # step against the wave slots the chip offers in one step time.
+    regime = None
+    if rank == 0:
+        try:
+            res = idx.stage_resources(a.batch, a.top_k, a.nprobe)
+        except Exception as e:  # noqa: BLE001
+            res = None
+            progress(f"stage_resources failed: {e}")
+        if res is not None:
+            SIMDS, VGPR_FILE, LDS_CU, MAX_WAVES = 1024, 512, 160 * 1024, 8
+            ov = prof.get("stage_ms_overlapped") or {}
+            step_ms = dt / a.steps * 1e3
+            stages_o, wave_ms, slot_ms = {}, 0.0, 0.0
+            for st_, r_ in res.items():
+                wpw = max(r_["threads"] // 64, 1)
+                waves = r_["workgroups"] * wpw
+                by_vgpr = min(MAX_WAVES, VGPR_FILE // max(8, (r_["vgprs"] + 7) // 8 * 8))
+                wg_per_cu = (by_vgpr * 4) // wpw
+                if r_["lds_bytes"]:
+                    wg_per_cu = min(wg_per_cu, LDS_CU // r_["lds_bytes"])
+                waves_per_simd = max(1, min(by_vgpr, wg_per_cu * wpw // 4))
+                d_al = serial["stage_ms"].get(st_) if serial else None
+                stages_o[st_] = dict(r_, waves=waves, waves_per_simd_by_registers=by_vgpr, waves_per_simd=waves_per_simd,
+                                     ms_alone=d_al, ms_overlapped=ov.get(st_))
+                if d_al:
+                    wave_ms += waves * d_al
+                    slot_ms += waves * d_al / waves_per_simd  # SIMD-milliseconds: the stage's waves at its own occupancy limit
+            regime = {"bound": "residency / latency: dependent phases per query keep waves resident while they wait; neither HBM "
+                               "(see `pruned`) nor issue slots",
+                      "stages": stages_o,
+                      "ms_per_step": step_ms,
+                      "sum_of_stage_ms_alone": (sum(v for v in serial["stage_ms"].values()) if serial else None),
+                      "overlap_gain": (sum(v for v in serial["stage_ms"].values()) / step_ms if serial else None),
+                      "resident_wave_us_per_query_upper": wave_ms * 1e3 / a.batch if wave_ms else None,
+                      "residency_model_ms_per_step": slot_ms / SIMDS if slot_ms else None,
+                      "residency_model_over_measured": (slot_ms / SIMDS / step_ms) if slot_ms else None,
+                      "issue_utilisation": None,
+                      "note": "residency_model_ms_per_step = sum over stages of (waves x duration alone) / (waves per SIMD its registers and LDS "
+                              "allow) / 1024 SIMDs: the step time if the chip were exactly full of these waves, each living as long as its "
+                              "launch does alone.  It OVER-estimates (a launch lasts as long as its slowest query; the mean workgroup is "
+                              "shorter), so model / measured a little above 1 = the pipelined rate is what the wave slots allow; "
+                              "ms_overlapped = a launch's duration while 12 streams overlap.  Resident wave-cycles and issue utilisation "
+                              "from SQ counters: rocprofv3 passes in profiles/r4/ (not measured in this run)"}
+
+    # Sensitivity of the headline to the data: the block-level bound and the lazy selection prune what the data lets them.
+    # Same index shape and workload, intrinsic dimension 16 ... 128 and SURVEY 8d's isotropic recipe (rank 0, headline only).
+    sensitivity = None
+    if extras and is_headline and os.environ.get("RBQ_BENCH_SENSITIVITY", "1") != "0":
+        try:
+            del x
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        rows = []
+        hdr_src = built if built is not None else small
+        for kind in ("mixture_id16", "mixture_id64", "mixture_id128"):
+            mx = Mixture(torch, dev, a.dim, a.nlist, kind, False)
+            xi = mx.draw(a.n, 20260105)
+            ci, ai = kmeans_gpu(torch, xi, a.nlist, a.kmeans_iters, 20260103)
+            idx2 = rq.IvfRabitqIndex.build_on_device(hdr_src.hdr_ptr, ci.cpu().numpy(), xi.data_ptr(), ai.to(torch.int32).contiguous().data_ptr(),
+                                                     a.n, hdr_src.t_const, device=local)
+            nb2 = min(NB, 8)
+            qi = mx.draw(nb2 * a.batch, 20260102).contiguous().view(nb2, a.batch, a.dim)
+            gti = exact_topk(torch, xi, qi.view(-1, a.dim), a.top_k, a.metric).cpu().numpy()
+            del xi
+            torch.cuda.empty_cache()
+            dti, _, pi = run_measured(idx2, qi, a.nprobe, 48, 4, ns, gather=False)
+            ri = recall_of(search_ids(idx2, qi, a.nprobe).reshape(-1, a.top_k), gti, a.top_k)
+            po = pruned_object(pi, pi["counter_steps"])
+            taps = lists_scanned(idx2, qi[0])
+            rows.append({"dataset": kind, "intrinsic_dim": mx.idim, "recall_at_k": ri, "queries_per_s": a.batch * 48 / statistics.median(dti),
+                         "block_skip_frac": po["block_skip_frac"], "lists_scanned_mean": taps, "nprobe": a.nprobe,
+                         "bytes_requested_per_launch": po["bytes_requested_per_launch"]})
+            idx2.close()
+        rows.append({"dataset": a.dataset, "intrinsic_dim": INTRINSIC_DIM, "recall_at_k": recall, "queries_per_s": value / world,
+                     "block_skip_frac": pruned["block_skip_frac"], "lists_scanned_mean": lists_scanned(idx, q_all[0]), "nprobe": a.nprobe,
+                     "bytes_requested_per_launch": pruned["bytes_requested_per_launch"], "role": "headline"})
+        sensitivity = {"by_dataset": sorted(rows, key=lambda r_: r_["intrinsic_dim"]),
+                       "note": "x = mean_k + 0.35 z A / sqrt(id) + 0.1 eps, z in R^id; same N, d, nlist, nprobe, top_k, batch, streams; 48-step "
+                               "regions; the isotropic recipe (intrinsic dimension = d) is in `datasets`"}
+
     what = f"N={a.n} d={a.dim}, nlist={a.nlist}, {a.bits}-bit, FhtKacRotator, {'L2' if a.metric == 0 else 'IP'}, nprobe={a.nprobe}, " \
            f"top_k={a.top_k}, batch={a.batch} per GPU"
     recall_ok = recall >= 0.95
@@ -962,6 +1120,9 @@ def main():
         "heap_restarts": int(idx.heap_restarts()),
         "roofline": roofline,
         "pruned": pruned,
+        "regime": regime,
+        "sensitivity": sensitivity,
+        "host_call": host_call,
         "pcie_inclusive": pcie,
         "latency": latency,
         "self_check": self_check,

@@ -250,6 +250,14 @@ void rbq_profile_set_sampling(rbq_index* idx, uint32_t every);
 /* Number of queries (since creation) whose probe selection fell back from the MFMA shortlist to the
  * all-lists canonical ranking (shortlist overflow / non-finite scores). Diagnostic. */
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
+/* Diagnostic: which kernel instantiation each stage (prep, rank, select, scan) launches for a call of nq queries with this top_k /
+ * nprobe on this index, and what it occupies: out[stage][6] = workgroups, threads per workgroup, VGPRs per lane, LDS bytes per
+ * workgroup (static + dynamic), scratch bytes per lane, 0.  Nothing is launched.  bench.py's `regime` object is built from it. */
+int rbq_debug_stage_resources(rbq_index* idx, uint64_t nq, uint32_t top_k, uint32_t nprobe, uint32_t* out);
+/* Replica arrays (process-wide, since start) that were copied between devices through the page-locked bounce buffer instead of
+ * hipMemcpyPeer: the path taken when the runtime refuses the peer copy, or for every replica copy when RBQ_FORCE_NO_PEER=1 is in
+ * the environment (test switch: the only way the path can run on a one-GPU box). Diagnostic. */
+uint64_t rbq_debug_bounce_copies(void);
 /* Number of queries (since creation) that met two bit-identical distances in their top-k and were therefore
  * re-run inside the scan kernel with the exact BinaryHeap emulation (src/ivf.rs:2078-2105 pushes into a
  * std BinaryHeap, whose tie behaviour depends on its layout). Diagnostic. */

@@ -18,6 +18,7 @@ hipError_t launch_prep(const PrepParams& p, int device, hipStream_t s) {
     if (p.rotator == 0 /* matrix: O(D^2) per query */ || p.wg_prep) {
         static LdsAttrCache attr;
         const size_t lds = (size_t)p.D * 4 * 2;
+        if (probe_stage(0, reinterpret_cast<const void*>(&k_prep), dim3(p.nq), kThreads, lds)) return hipSuccess;
         hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_prep), lds, device);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_prep, dim3(p.nq), dim3(kThreads), lds, s, p.queries, p.dim, p.D, p.Dc, p.rotator, p.rot_blob, p.trunc,
@@ -26,6 +27,7 @@ hipError_t launch_prep(const PrepParams& p, int device, hipStream_t s) {
         static LdsAttrCache attr;
         const uint32_t qpw = kThreads / 64;
         const size_t lds = (size_t)p.D * 4 * 2 * qpw + p.D / 2;
+        if (probe_stage(0, reinterpret_cast<const void*>(&k_prep_wave), dim3((p.nq + qpw - 1) / qpw), kThreads, lds)) return hipSuccess;
         hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_prep_wave), lds, device); // 66.5 KB at D = 2048
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_prep_wave, dim3((p.nq + qpw - 1) / qpw), dim3(kThreads), lds, s, p.queries, p.nq, p.dim, p.D, p.Dc,
@@ -36,6 +38,7 @@ hipError_t launch_prep(const PrepParams& p, int device, hipStream_t s) {
 
 hipError_t launch_rank_exact(const RankParams& p, hipStream_t s) {
     dim3 grid((p.nlist + 31) / 32, (p.nq + 31) / 32);
+    if (probe_stage(1, p.metric == 0 ? reinterpret_cast<const void*>(&k_rank_scores<0>) : reinterpret_cast<const void*>(&k_rank_scores<1>), grid, kThreads, 0)) return hipSuccess;
     if (p.metric == 0) hipLaunchKernelGGL(k_rank_scores<0>, grid, dim3(kThreads), 0, s, p.rot, p.cent, p.nq, p.nlist, p.D, p.scores);
     else hipLaunchKernelGGL(k_rank_scores<1>, grid, dim3(kThreads), 0, s, p.rot, p.cent, p.nq, p.nlist, p.D, p.scores);
     return hipGetLastError();
@@ -48,6 +51,7 @@ template <int M, int TM, int TN, int WM, int WN>
 hipError_t launch_rank_split(const RankParams& p, dim3 grid, int device, hipStream_t s) {
     static LdsAttrCache attr;
     const size_t lds = (size_t)(2 * 32 * TM * WM + 2 * 32 * TN * WN) * 80 * 2; // two slabs of 32, rows of 80 B
+    if (probe_stage(1, reinterpret_cast<const void*>(&k_rank_bf16_db<M, TM, TN, WM, WN>), grid, 64 * WM * WN, lds)) return hipSuccess;
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_rank_bf16_db<M, TM, TN, WM, WN>), lds, device);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_rank_bf16_db<M, TM, TN, WM, WN>), grid, dim3(64 * WM * WN), lds, s, p.rot_hi, p.rot_lo, p.cent_hi, p.cent_lo,
@@ -56,6 +60,7 @@ hipError_t launch_rank_split(const RankParams& p, dim3 grid, int device, hipStre
 }
 template <int M, int TW>
 hipError_t launch_rank_f32(const RankParams& p, dim3 grid, hipStream_t s) {
+    if (probe_stage(1, reinterpret_cast<const void*>(&k_rank_mfma<M, TW>), grid, 256, 0)) return hipSuccess;
     hipLaunchKernelGGL((k_rank_mfma<M, TW>), grid, dim3(256), 0, s, p.rot, p.cent, p.consts, p.cnorm2, p.nq, p.nlist, p.D, p.scores);
     return hipGetLastError();
 }
@@ -79,6 +84,7 @@ hipError_t launch_select_exact(const SelectParams& p, int device, hipStream_t s,
     // key_window != null: [nq][np2] u64 in global memory (nprobe > kNprobeMax)
     const size_t lds = (key_window ? 0 : (size_t)np2 * 8) + (size_t)p.D * 4 + kThreads * 4;
     static LdsAttrCache attr; // nprobe > 4096: more than the default 64 KB of dynamic LDS
+    if (probe_stage(2, reinterpret_cast<const void*>(&k_select), dim3(p.nq), kThreads, lds)) return hipSuccess;
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_select), lds, device);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_select, dim3(p.nq), dim3(kThreads), lds, s, (const float*)p.scores, p.nlist, p.nprobe, np2, p.metric, p.rot,
@@ -91,6 +97,7 @@ namespace {
 template <int RM>
 hipError_t launch_select_rm(const SelectParams& p, const SelectGeom& g, size_t lds, int device, hipStream_t s) {
     static LdsAttrCache attr;
+    if (probe_stage(2, reinterpret_cast<const void*>(&k_select_mfma<RM>), dim3(p.nq), kThreads, lds)) return hipSuccess;
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_select_mfma<RM>), lds, device);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_select_mfma<RM>, dim3(p.nq), dim3(kThreads), lds, s, p, g);

@@ -11,6 +11,7 @@
 namespace rbq {
 
 #ifndef RBQ_SCAN_TU2
+StageProbes*& stage_probes() { static thread_local StageProbes* p = nullptr; return p; }
 hipError_t LdsAttrCache::ensure(const void* fn, size_t lds, int device) {
     if (lds <= 48 * 1024) return hipSuccess; // default dynamic-LDS limit
     const int d = device & 15;
@@ -29,6 +30,7 @@ namespace {
 template <int DT, int EX, int TR>
 hipError_t launch_scan_r(const ScanParams& P, uint32_t nq, size_t lds, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     static LdsAttrCache attr;
+    if (probe_stage(3, reinterpret_cast<const void*>(&k_scan<DT, EX, TR>), dim3(nq), kScanThreads, lds)) return hipSuccess;
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_scan<DT, EX, TR>), lds, device);
     if (e != hipSuccess) return e;
     if (ev0) hipExtLaunchKernelGGL((k_scan<DT, EX, TR>), dim3(nq), dim3(kScanThreads), lds, s, ev0, ev1, 0, P);

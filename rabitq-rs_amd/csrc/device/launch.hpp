@@ -20,6 +20,18 @@ struct LdsAttrCache {
     hipError_t ensure(const void* fn, size_t lds, int device);
 };
 
+// Launch probe (diagnostic: rbq_debug_stage_resources).  While the calling thread has a probe installed, the four stage
+// launchers record WHICH kernel instantiation they would launch, and its geometry, instead of launching it.
+struct KernelProbe { const void* fn = nullptr; uint32_t grid_x = 0, grid_y = 0, block = 0; size_t dyn_lds = 0; };
+struct StageProbes { KernelProbe k[4]; }; // prep, rank, select, scan
+StageProbes*& stage_probes(); // this thread's probe (null: launch normally)
+inline bool probe_stage(int stage, const void* fn, dim3 grid, uint32_t block, size_t lds) {
+    StageProbes* p = stage_probes();
+    if (!p) return false;
+    p->k[stage].fn = fn; p->k[stage].grid_x = grid.x; p->k[stage].grid_y = grid.y; p->k[stage].block = block; p->k[stage].dyn_lds = lds;
+    return true;
+}
+
 struct PrepParams {
     const float* queries; // [nq][dim]
     uint32_t nq, dim, D, Dc;
@@ -80,8 +92,9 @@ struct SelectParams {
     uint32_t top_k, ex_bits;
     int lazy;                     // 0: every probed list is scored and streamed (round-2 behaviour)
     int exact_members;            // diagnostics: dead_skipped and the probed-vector count must be exact
-    int tub_scale_log2;           // TEST ONLY (debug option lazy_tub_scale_log2, default 0): T_ub is multiplied by 2^this — a
-                                  // deliberately WRONG bound, so that the bound_violations audit can be shown to catch one
+    int fault_dead_all;           // TEST ONLY (debug option lazy_fault_inject, default 0): T_ub := -inf — every list behind the head is
+                                  // declared dead whatever its bounds say: a deliberately WRONG selection, so that the
+                                  // bound_violations audit can be shown to catch one
 };
 // key_window: null, or [nq][select_exact_np2(nprobe)] u64 in global memory (nprobe > kNprobeMax: the exact path with its key
 // window outside the LDS — slow, but every nprobe up to n_lists is served, as the reference does, src/ivf.rs:1791)

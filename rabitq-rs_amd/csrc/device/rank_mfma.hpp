@@ -1046,7 +1046,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 if (cum >= P.top_k) atomicMin(reinterpret_cast<int*>(&s_tub), total_key(myU));
             }
             __syncthreads();
-            const float T_ub = P.tub_scale_log2 ? ldexpf(key_to_float((int32_t)s_tub), P.tub_scale_log2) : key_to_float((int32_t)s_tub);
+            const float T_ub = P.fault_dead_all ? -INFINITY : key_to_float((int32_t)s_tub); // (fault_dead_all: test-only fault injection)
             const float cost_maxh = key_to_float((int32_t)s_maxh);
             lazy = T_ub < INFINITY;
             dbg_tub = __float_as_uint(T_ub);

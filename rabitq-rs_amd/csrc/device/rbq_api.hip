@@ -169,7 +169,7 @@ struct Replica {
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
-    int lazy_tub_scale_log2 = 0; // TEST ONLY: makes the select-time bound wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
+    bool lazy_fault_inject = false; // TEST ONLY: makes the lazy selection wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     bool profile_counters = true; // an open profile keeps the traffic counters (option profile_counters = 0: stage timings only —
                                   // the counters cost the pipelined run 2-3 %, bench.py collects them in a pass of their own)
@@ -383,19 +383,28 @@ int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
 // Device-to-device copy between two replicas' devices: peer copy over xGMI when the runtime can (peer access is enabled
 // when the devices report it; hipMemcpyPeer itself stages through the host otherwise); if that fails, an explicit bounce
 // through a page-locked host buffer, 64 MB at a time.
+// RBQ_FORCE_NO_PEER=1 in the environment (read when a handle replicates): every replica copy takes the bounce path, also
+// between two replicas on ONE device — the only way the path can run on a one-GPU box (tests/test_gpu_round4.py).
+std::atomic<uint64_t> g_bounce_copies{0}; // replica arrays copied through the page-locked bounce buffer (rbq_debug_bounce_copies)
 hipError_t copy_cross_device(void* dst, int ddev, const void* src, int sdev, size_t bytes) {
     if (!bytes) return hipSuccess;
-    if (ddev == sdev) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice);
-    int can = 0;
-    if (hipDeviceCanAccessPeer(&can, ddev, sdev) == hipSuccess && can) {
-        const hipError_t pe = hipDeviceEnablePeerAccess(sdev, 0); // (current device = ddev)
-        if (pe != hipSuccess) (void)hipGetLastError();            // already enabled, or refused: the copy below decides
-    } else {
+    const char* fnp = std::getenv("RBQ_FORCE_NO_PEER");
+    const bool no_peer = fnp && fnp[0] == '1';
+    hipError_t e = hipSuccess;
+    if (!no_peer) {
+        if (ddev == sdev) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice);
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ddev, sdev) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(sdev, 0); // (current device = ddev)
+            if (pe != hipSuccess) (void)hipGetLastError();            // already enabled, or refused: the copy below decides
+        } else {
+            (void)hipGetLastError();
+        }
+        e = hipMemcpyPeer(dst, ddev, src, sdev, bytes);
+        if (e == hipSuccess) return e;
         (void)hipGetLastError();
     }
-    hipError_t e = hipMemcpyPeer(dst, ddev, src, sdev, bytes);
-    if (e == hipSuccess) return e;
-    (void)hipGetLastError();
+    g_bounce_copies.fetch_add(1, std::memory_order_relaxed);
     const size_t CH = (size_t)64 << 20;
     void* bounce = nullptr;
     e = hipHostMalloc(&bounce, std::min(bytes, CH), hipHostMallocPortable);
@@ -1062,7 +1071,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     // exists) and not when every probed block is to be streamed
     sp.lazy = (ix->lazy_select && !d_filter && !ix->no_block_bound) ? 1 : 0;
     sp.exact_members = d_diag ? 1 : 0;
-    sp.tub_scale_log2 = ix->lazy_tub_scale_log2;
+    sp.fault_dead_all = ix->lazy_fault_inject ? 1 : 0;
     if (ix->exact_rank || big_nprobe) {
         uint64_t* kw = nullptr;
         if (big_nprobe) {
@@ -1078,7 +1087,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
                          /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
         return rc;
-    if (ix->rerank) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
+    if (ix->rerank && !stage_probes()) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
         HIP_TRY(launch_rerank(d_queries, (uint32_t)nq, ix->dim, (const float*)ix->raw.p, ix->n_raw, ix->metric, top_k, d_ids, d_scores,
                               d_counts, stream));
     return RBQ_OK;
@@ -1183,7 +1192,8 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         if (j >= nlanes && (rc = deliver(w, j - nlanes))) return rc;
         const uint64_t q0 = plan[j].first, n = plan[j].second;
         const OutPack op(n, top_k, diag != nullptr);
-        if (!zero_copy && (rc = w->queries.ensure(n * query_dim * 4))) return rc;
+        const bool staged_in_hbm = !(c_queries || (zero_copy && !in_pinned)); // an H2D copy into the lane's device buffer
+        if (staged_in_hbm && (rc = w->queries.ensure(n * query_dim * 4))) return rc;
         const float* src = queries + q0 * query_dim;
         tp = clk::now();
         const float* d_q = (const float*)w->queries.p; // where k_prep reads this sub-batch
@@ -1738,7 +1748,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_lanes")) ix->host_lanes = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_subbatch")) ix->host_subbatch = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
-        else if (!std::strcmp(name, "lazy_tub_scale_log2")) ix->lazy_tub_scale_log2 = value;
+        else if (!std::strcmp(name, "lazy_fault_inject")) ix->lazy_fault_inject = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
@@ -1760,6 +1770,36 @@ static uint64_t read_counter(const rbq_index* h, int slot) {
     return tot;
 }
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* h) { return read_counter(h, 0); }
+// Which kernel instantiation each of the four stages launches for a call of this shape, and what it occupies.
+// out[stage][6] = workgroups, threads per workgroup, VGPRs per lane, LDS bytes per workgroup (static + dynamic), scratch bytes per
+// lane, 0; stages in the order prep, rank, select, scan.  Nothing is launched.
+int rbq_debug_stage_resources(rbq_index* h, uint64_t nq, uint32_t top_k, uint32_t nprobe, uint32_t* out) {
+    g_err.clear();
+    RBQ_GUARD_BEGIN
+    if (!h || h->reps.empty() || !out || nq == 0 || nq > 0x7fffffffull || top_k == 0) return fail(RBQ_INVALID_CONFIG, "bad argument");
+    Replica* ix = h->reps[0];
+    DeviceGuard g(ix->device);
+    if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
+    Workspace w; // scratch buffers are sized like a real call's (and freed on return); no kernel runs
+    StageProbes probes;
+    stage_probes() = &probes;
+    const int rc = search_device(ix, &w, nullptr, nq, top_k, nprobe, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    stage_probes() = nullptr;
+    w.release();
+    if (rc) return rc;
+    for (int st = 0; st < 4; ++st) {
+        const KernelProbe& k = probes.k[st];
+        hipFuncAttributes fa;
+        if (!k.fn) return fail(RBQ_DEVICE, "stage was not probed");
+        HIP_TRY(hipFuncGetAttributes(&fa, k.fn));
+        uint32_t* o = out + 6 * st;
+        o[0] = k.grid_x * (k.grid_y ? k.grid_y : 1u); o[1] = k.block; o[2] = (uint32_t)fa.numRegs;
+        o[3] = (uint32_t)(fa.sharedSizeBytes + k.dyn_lds); o[4] = (uint32_t)fa.localSizeBytes; o[5] = 0;
+    }
+    return RBQ_OK;
+    RBQ_GUARD_END
+}
+uint64_t rbq_debug_bounce_copies(void) { return g_bounce_copies.load(std::memory_order_relaxed); }
 uint64_t rbq_debug_heap_restarts(const rbq_index* h) { return read_counter(h, 1); }
 
 /* Diagnostic: copy an intermediate buffer of the workspace bound to `hip_stream` (after the caller synchronised). */

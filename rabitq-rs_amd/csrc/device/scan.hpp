@@ -1058,6 +1058,9 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
                     lb = est;                                   // f_error row and g_error are zero
                 } else if (!finite_f(lb)) {
                     lb = P.metric == 0 ? 0.0f : -(m_c.dotqc + qc.qnorm);
+                    // the reference skips iff `lower_bound >= distk` (src/ivf.rs:2054): a NaN bound (NaN query, inner product)
+                    // is never skipped.  -inf decides every such test the same way and keeps `lb < T` usable below.
+                    if (lb != lb) lb = -INFINITY;
                 }
                 surv = valid && (lb < T);
             }
@@ -1126,6 +1129,7 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
                         lb = est;                                   // f_error row and g_error are zero
                     } else if (!finite_f(lb)) {
                         lb = P.metric == 0 ? 0.0f : -(m_c[i].dotqc + qc.qnorm);
+                        if (lb != lb) lb = -INFINITY; // (NaN is never `>= distk`: see the one-block form above)
                     }
                     surv = valid && (lb < T);
                 }

@@ -64,6 +64,10 @@ def lib():
         L.rbq_profile_scan_bytes.argtypes = [vp]
         L.rbq_debug_rank_fallbacks.restype = C.c_uint64
         L.rbq_debug_rank_fallbacks.argtypes = [vp]
+        L.rbq_debug_stage_resources.restype = C.c_int
+        L.rbq_debug_stage_resources.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+        L.rbq_debug_bounce_copies.restype = C.c_uint64
+        L.rbq_debug_bounce_copies.argtypes = []
         L.rbq_index_build_device.restype = C.c_int
         L.rbq_index_build_device.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_float, C.c_int, vp]
         L.rbq_debug_copy_index.restype = C.c_int
@@ -301,6 +305,13 @@ class IvfRabitqIndex:
 
     def set_option(self, name, value):
         _check(lib().rbq_debug_set_option(self._h, name.encode(), int(value)))
+
+    def stage_resources(self, nq, top_k, nprobe):
+        """{stage: {workgroups, threads, vgprs, lds_bytes, scratch_bytes}} of the kernels a call of this shape launches (nothing runs)"""
+        out = np.zeros((4, 6), np.uint32)
+        _check(lib().rbq_debug_stage_resources(self._h, nq, top_k, nprobe, out.ctypes.data))
+        return {s: {"workgroups": int(o[0]), "threads": int(o[1]), "vgprs": int(o[2]), "lds_bytes": int(o[3]), "scratch_bytes": int(o[4])}
+                for s, o in zip(("prep", "rank", "select", "scan"), out)}
 
     def rank_fallbacks(self):
         return lib().rbq_debug_rank_fallbacks(self._h)

@@ -53,7 +53,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_query_sharding_and_topk_gather_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_query_sharding_and_topk_gather(tmp_path, world):
+    """world 2, and world 8 = the shape of the driver's 8-GPU run (eight contiguous query shards, one bucketed all_gather):
+    the gathered blocks are the unsharded result, rank order = query order"""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert open(tmp_path / "ok").read() == "1"
