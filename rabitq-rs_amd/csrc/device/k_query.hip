@@ -2,6 +2,7 @@
 // (rotate + constants + LUT), the centroid-ranking GEMMs, probe selection and the MSTG probe list.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "launch.hpp"
@@ -135,7 +136,16 @@ hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) 
 #endif
     const size_t rowsN = RBQ_SEL_ROWS * ((size_t)p.D + 8) * 4 + 16;
     g.stage_rows = (p.lazy && lds + rowsN <= 64 * 1024) ? (uint32_t)RBQ_SEL_ROWS : 0u;
-    if (g.stage_rows) lds += rowsN;
+    // exact head evaluation (rank_mfma.hpp, step 3b): its scratch shares the rows' region (used before the scoring round)
+    g.hx_nv = 0;
+    size_t regionN = g.stage_rows ? rowsN : 0;
+    if (p.lazy && p.head_exact && p.lut && p.top_k <= kHxMaxVec && p.D % 16 == 0) {
+        uint32_t nv = (uint32_t)((16384u * 8u / p.Dc) / 32u * 32u);
+        nv = nv < 64u ? 64u : (nv > kHxMaxVec ? kHxMaxVec : nv);
+        const size_t hxN = (hx_scratch_bytes(p.D, p.Dc, p.ex_bits, nv) + 15) & ~(size_t)15;
+        if (lds + std::max(regionN, hxN) <= 64 * 1024) { g.hx_nv = nv; regionN = std::max(regionN, hxN); }
+    }
+    lds += regionN;
     g.cand_cap = (uint32_t)(((g.stage ? (size_t)p.nprobe * 16 : 0) + (g.stage_rows ? rowsN - 16 : 0)) / 8); // (RM == 0 prefilter window)
     {   // diagnostic: extra dynamic LDS per workgroup (occupancy experiments)
         static const size_t pad = [] { const char* e = std::getenv("RBQ_SEL_LDS_PAD"); return e ? (size_t)std::atol(e) : (size_t)0; }();

@@ -92,6 +92,13 @@ struct SelectParams {
     uint32_t top_k, ex_bits;
     int lazy;                     // 0: every probed list is scored and streamed (round-2 behaviour)
     int exact_members;            // diagnostics: dead_skipped and the probed-vector count must be exact
+    // exact head evaluation (round 4): a select-time bound of the k-th distance from REAL estimates of the nearest list's first vectors
+    const uint8_t* lut;           // [nq][4Dc] the queries' u8 LUTs (k_prep), device codebook order
+    const uint8_t* blocks;        // the index's block records / ex codes / ex factors, as k_scan reads them
+    const uint8_t* ex_codes;
+    const float *f_add_ex, *f_rescale_ex;
+    uint32_t Dc;
+    int head_exact;               // 0: Cauchy-Schwarz bound only (round 3)
     int fault_dead_all;           // TEST ONLY (debug option lazy_fault_inject, default 0): T_ub := -inf — every list behind the head is
                                   // declared dead whatever its bounds say: a deliberately WRONG selection, so that the
                                   // bound_violations audit can be shown to catch one

@@ -368,7 +368,11 @@ struct SelectGeom {
     int stage;           // per-probe geometry staged in LDS
     uint32_t stage_rows; // centroid rows the LDS scorer stages at a time (0: no room, pair scorer only)
     uint32_t cand_cap;   // RM == 0: (key, cid) candidates that fit the LDS behind `part` before it is used for anything else
+    uint32_t hx_nv;      // exact head evaluation: vectors of the nearest list whose 1-bit estimate is evaluated (0: off); its LDS
+                         // scratch (u8 LUT | zero-padded query | three floats per vector) shares the region of the LDS scorer's rows
 };
+constexpr uint32_t kHxTrigger = 6;   // lists alive beyond the head under the Cauchy-Schwarz bound that make the exact evaluation worth its cost
+constexpr uint32_t kHxMaxVec = 256;  // one thread per vector
 
 // ---- canonical scores of shortlist entries ----------------------------------------------------------------------------
 // Both scorers overwrite keys[e] (approximate key | cid) with the EXACT (score, cid) key of entry e = idx_of(j), j < m, and
@@ -603,6 +607,159 @@ __device__ __forceinline__ void sort_keys(uint64_t* keys, uint32_t n, uint32_t c
                 __syncthreads();
             }
     }
+}
+
+
+// ---- exact head evaluation (k_select_mfma step 3b) -----------------------------------------------------------------------
+// LDS scratch layout (shares the region of the LDS scorer's rows): lut[4 Dc] u8 | sq[ex_qlen] f32 | est[nv] | lb[nv] | ip[nv] | U[nv]
+__host__ __device__ inline size_t hx_scratch_bytes(uint32_t D, uint32_t Dc, uint32_t ex_bits, uint32_t nv) {
+    return (size_t)Dc * 4 + (ex_bits ? (size_t)ex_qlen(D, ex_bits) * 4 : 0) + (size_t)nv * 16 + 16;
+}
+__device__ __forceinline__ uint32_t hx_look8(uint32_t x, const uint8_t* p) { // scan.hpp look8 on a plain LDS pointer
+    uint32_t s = p[x & 15u];
+    s += p[16 + ((x >> 4) & 15u)];
+    s += p[32 + ((x >> 8) & 15u)];
+    s += p[48 + ((x >> 12) & 15u)];
+    s += p[64 + ((x >> 16) & 15u)];
+    s += p[80 + ((x >> 20) & 15u)];
+    s += p[96 + ((x >> 24) & 15u)];
+    s += p[112 + (x >> 28)];
+    return s;
+}
+__device__ __forceinline__ bool hx_tame(float x) { return fabsf(x) < 1e30f; } // far from overflow: the exact value next to it is finite too
+// Returns T' (see the kernel), +inf when the list is too short or too few of its vectors have finite bounds.  Every thread of the
+// workgroup calls it and gets the same value.  scratch: the LDS region above; part / hist: 256 words of LDS scratch each.
+template <class CostOf>
+__device__ __forceinline__ float head_exact_bound(const SelectParams& P, const SelectGeom& G, const QueryConsts& qc, const uint64_t* keys,
+                                                  const uint32_t* s_head, const uint32_t* s_hgb, const uint32_t* s_hn, const float* s_hcn,
+                                                  uint32_t h, float eps, unsigned char* scratch, const float* qrot, uint32_t* part, uint32_t* hist,
+                                                  uint32_t q, uint32_t tid, CostOf&& cost_of) {
+    const uint32_t D = P.D, Dc = P.Dc, ex_bits = P.ex_bits, top_k = P.top_k;
+    // the nearest head list by approximate cost (any head list would do: all of them precede every dead list)
+    uint32_t r0 = 0, kbest = 0xffffffffu;
+    for (uint32_t r = 0; r < h; ++r) {
+        const uint32_t k32 = (uint32_t)(keys[s_head[r]] >> 32);
+        if (k32 < kbest) { kbest = k32; r0 = r; }
+    }
+    const float ci = cost_of(kbest);
+    const float g_add = ci + 1.01f * eps; // upper end (estimates and refined distances grow with g_add)
+    float ge_lo, ge_hi;
+    if (P.metric == 0) { ge_lo = sqrtf(fmaxf(ci - 1.01f * eps, 0.0f)); ge_hi = sqrtf(fmaxf(g_add, 0.0f)); }
+    else { const float da = qc.qnorm2 + s_hcn[r0] + 2.0f * ci; ge_lo = sqrtf(fmaxf(da - 4.0f * eps, 0.0f)); ge_hi = sqrtf(fmaxf(da + 4.0f * eps, 0.0f)); }
+    const uint32_t gb = s_hgb[r0], nvec = s_hn[r0];
+    const uint32_t nv = nvec < G.hx_nv ? nvec : G.hx_nv;
+    if (nv < top_k || top_k == 0 || !hx_tame(g_add) || !hx_tame(ge_hi)) return INFINITY; // (uniform)
+    uint8_t* lutL = scratch;
+    float* sq = reinterpret_cast<float*>(scratch + (size_t)Dc * 4);
+    const uint32_t qlen = ex_bits ? ex_qlen(D, ex_bits) : 0u;
+    float* vEst = sq + qlen;
+    float* vLb = vEst + nv;
+    float* vIp = vLb + nv;
+    float* vU = vIp + nv;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
+        uint4* dst = reinterpret_cast<uint4*>(lutL);
+        for (uint32_t i = tid; i < Dc / 4; i += kThreads) dst[i] = src[i];
+        for (uint32_t i = tid; i < qlen; i += kThreads) sq[i] = i < D ? qrot[i] : 0.0f;
+    }
+    __syncthreads();
+    const size_t stride = (size_t)Dc * 4 + 384;
+    // phase 1: thread v = vector v of the list: accumulate + epilogue of k_scan (lb_of), bounds' ends of g_add / g_err
+    if (tid < nv) {
+        const uint32_t b = tid >> 5, l32 = tid & 31u;
+        const uint8_t* blk = P.blocks + (size_t)(gb + b) * stride;
+        const uint32_t G16 = Dc >> 7;
+        const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
+        uint32_t acc = 0;
+        for (uint32_t g = 0; g < G16; ++g) {
+            const uint4 x = cp[g * 32];
+            acc += hx_look8(x.x, lutL + g * 512) + hx_look8(x.y, lutL + g * 512 + 128) + hx_look8(x.z, lutL + g * 512 + 256) +
+                   hx_look8(x.w, lutL + g * 512 + 384);
+        }
+        if (Dc & 64u) {
+            const uint2 y = *(reinterpret_cast<const uint2*>(blk + G16 * 512) + l32);
+            acc += hx_look8(y.x, lutL + G16 * 512) + hx_look8(y.y, lutL + G16 * 512 + 128);
+        }
+        const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
+        const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
+        const float ip = fmaf(qc.delta, (float)(acc & 0xffffu), qc.sum_vl);
+        const float tt = ip + qc.k1x;
+        const float rs = f_rescale * tt;
+        float est = f_add + g_add;
+        const float e0 = est;
+        est = est + rs;
+        const float er = fminf(f_error * ge_lo, f_error * ge_hi);
+        const float lb = est - er;
+        const bool ok = hx_tame(f_add) && hx_tame(f_rescale) && hx_tame(f_error) && hx_tame(ip) && hx_tame(rs) && hx_tame(e0) && hx_tame(est) &&
+                        hx_tame(f_error * ge_lo) && hx_tame(f_error * ge_hi) && hx_tame(lb) && qc.amax <= 65535.0f;
+        vEst[tid] = ok ? est : INFINITY;
+        vLb[tid] = lb;
+        vIp[tid] = ip;
+    }
+    __syncthreads();
+    float* res = reinterpret_cast<float*>(part);
+    if (tid == 0) res[0] = INFINITY;
+    if (ex_bits == 0) { // distance = estimate: U_v = max(est, lb); T' = the k-th smallest
+        if (tid < nv) vU[tid] = vEst[tid] < INFINITY ? fmaxf(vEst[tid], vLb[tid]) : INFINITY;
+        __syncthreads();
+        if (tid < nv) {
+            const float my = vU[tid];
+            uint32_t rk = 0;
+            for (uint32_t j = 0; j < nv; ++j) { const float o = vU[j]; rk += (o < my || (o == my && j < tid)) ? 1u : 0u; }
+            if (rk == top_k - 1u) res[0] = my;
+        }
+        __syncthreads();
+        const float r = res[0];
+        __syncthreads(); // (every thread has read the result before anyone reuses the scratch words)
+        return r;
+    }
+    // phase 2: the R smallest estimates are refined (16 lanes per vector, the reference's FMA order: bit-identical to k_scan)
+    const uint32_t R0 = 2u * top_k > 16u ? 2u * top_k : 16u;
+    const uint32_t R = R0 < nv ? R0 : nv;
+    if (tid < nv) {
+        const float my = vEst[tid];
+        uint32_t rk = 0;
+        for (uint32_t j = 0; j < nv; ++j) { const float o = vEst[j]; rk += (o < my || (o == my && j < tid)) ? 1u : 0u; }
+        if (rk < R) hist[rk] = tid;
+    }
+    __syncthreads();
+    {
+        const uint32_t grp = tid >> 4, gl = tid & 15u;
+        const uint32_t nunits = ex_w4(D, ex_bits);
+        const size_t exb = ex_bytes_dev(D, ex_bits);
+        for (uint32_t j = grp; j < R; j += kThreads / 16) {
+            const uint32_t v = hist[j];
+            const uint32_t slot = (gb + (v >> 5)) * 32u + (v & 31u);
+            const uint8_t* ex = P.ex_codes + (size_t)slot * exb;
+            float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, sq, gl, nunits) : ex_dot_units<2>(ex, sq, gl, nunits);
+            sacc = group16_reduce(sacc);
+            if (gl == 0) {
+                const float fa = P.f_add_ex[slot], fr = P.f_rescale_ex[slot];
+                float tt2 = qc.scale * vIp[v];
+                const float t0 = tt2;
+                tt2 = tt2 + sacc;
+                const float t1 = tt2;
+                tt2 = tt2 + qc.kbx;
+                const float a = fa + g_add;
+                const float m = fr * tt2;
+                const float d = a + m;
+                const bool ok = vEst[v] < INFINITY && hx_tame(fa) && hx_tame(fr) && hx_tame(t0) && hx_tame(sacc) && hx_tame(t1) && hx_tame(tt2) &&
+                                hx_tame(a) && hx_tame(m) && hx_tame(d);
+                vU[j] = ok ? fmaxf(d, vLb[v]) : INFINITY;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < R) {
+        const float my = vU[tid];
+        uint32_t rk = 0;
+        for (uint32_t j = 0; j < R; ++j) { const float o = vU[j]; rk += (o < my || (o == my && j < tid)) ? 1u : 0u; }
+        if (rk == top_k - 1u) res[0] = my;
+    }
+    __syncthreads();
+    const float r = res[0];
+    __syncthreads(); // (every thread has read the result before anyone reuses the scratch words)
+    return r;
 }
 
 constexpr uint32_t kSelHead = 4;       // nearest lists that are always scored and scanned: their blocks give the bound T_ub
@@ -1053,30 +1210,52 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             if (tid < h) s_todo[tid] = s_head[tid];
             LSTAMP(3);
             if (lazy) {
-                // 3. classification of the entries beyond the head; what is alive goes straight to the to-score list (`hist`)
-                for (uint32_t u = 0; u < nown && tid < n; ++u) {
-                    const uint32_t i = tid + u * kThreads;
-                    if (is_head(i)) continue;
-                    const uint64_t key = keys[i];
-                    const uint32_t cid = (uint32_t)key;
-                    const float ci = cost_of((uint32_t)(key >> 32));
-                    const float clo = ci - 1.01f * eps, chi = ci + 1.01f * eps; // (1.01: the rounding of these sums)
-                    float ge_lo, ge_hi;
-                    if (metric == 0) { ge_lo = sqrtf(fmaxf(clo, 0.0f)); ge_hi = sqrtf(fmaxf(chi, 0.0f)); }
-                    else { // canonical squared distance = |q|^2 + |c|^2 - 2 dot, within 4 eps of this evaluation (rank_mfma.hpp header)
-                        const float da = qc.qnorm2 + (u == 0 ? cn_own : P.cnorm2[cid]) + 2.0f * ci;
-                        ge_lo = sqrtf(fmaxf(da - 4.0f * eps, 0.0f)); ge_hi = sqrtf(fmaxf(da + 4.0f * eps, 0.0f));
+                // 3. classification of the entries beyond the head against a bound T; what is alive goes straight to the to-score list
+                auto classify = [&](float T) {
+                    for (uint32_t u = 0; u < nown && tid < n; ++u) {
+                        const uint32_t i = tid + u * kThreads;
+                        if (is_head(i)) continue;
+                        const uint64_t key = keys[i];
+                        const uint32_t cid = (uint32_t)key;
+                        const float ci = cost_of((uint32_t)(key >> 32));
+                        const float clo = ci - 1.01f * eps, chi = ci + 1.01f * eps; // (1.01: the rounding of these sums)
+                        float ge_lo, ge_hi;
+                        if (metric == 0) { ge_lo = sqrtf(fmaxf(clo, 0.0f)); ge_hi = sqrtf(fmaxf(chi, 0.0f)); }
+                        else { // canonical squared distance = |q|^2 + |c|^2 - 2 dot, within 4 eps of this evaluation (rank_mfma.hpp header)
+                            const float da = qc.qnorm2 + (u == 0 ? cn_own : P.cnorm2[cid]) + 2.0f * ci;
+                            ge_lo = sqrtf(fmaxf(da - 4.0f * eps, 0.0f)); ge_hi = sqrtf(fmaxf(da + 4.0f * eps, 0.0f));
+                        }
+                        const BlockSummary ls = u == 0 ? ls_own : P.lsum[cid];
+                        const bool dead = clo > cost_maxh && list_bound_reaches(ls, clo, chi, ge_lo, ge_hi, qc, T);
+                        if (dead) m_dead |= 1ull << u;
+                        else {
+                            if (!((m_certain >> u) & 1ull)) s_flag = 1u; // a zone list is alive
+                            const uint32_t p = atomicAdd(&s_need, 1u);
+                            if (p < kSelTodoMax) s_todo[p] = i;
+                        }
                     }
-                    const BlockSummary ls = u == 0 ? ls_own : P.lsum[cid];
-                    const bool dead = clo > cost_maxh && list_bound_reaches(ls, clo, chi, ge_lo, ge_hi, qc, T_ub);
-                    if (dead) m_dead |= 1ull << u;
-                    else {
-                        if (!((m_certain >> u) & 1ull)) s_flag = 1u; // a zone list is alive
-                        const uint32_t p = atomicAdd(&s_need, 1u);
-                        if (p < kSelTodoMax) s_todo[p] = i;
+                    __syncthreads();
+                };
+                classify(T_ub);
+                // 3b. EXACT HEAD EVALUATION (round 4).  The Cauchy-Schwarz bound ignores the direction of q - c: T_ub is 4-5 x the
+                // final k-th distance, and at small dimensions (or 65 536 lists) most probed lists stay alive under it.  When
+                // more than kHxTrigger do, the first vectors of the NEAREST head list are evaluated for real: thread v
+                // computes vector v's 1-bit estimate and lower bound exactly as k_scan will (same u8 LUT, same operation
+                // sequence, g_add / g_err at the ends of their intervals that make both LARGER), the 2k smallest estimates
+                // are refined with the ex codes in the reference's FMA order, U_v := max(refined distance, lower bound), and
+                // T' := the k-th smallest U_v.  Same claim as for T_ub (any k vectors the reference visits before the dead
+                // lists will do): each of them, if it sees a threshold > T' >= lb_v, is evaluated and pushed with a distance
+                // <= T'.  Lists are then classified again against min(T_ub, T').
+                if (G.hx_nv && P.head_exact && s_need - h > kHxTrigger) { // (uniform: s_need is final behind classify's barrier)
+                    const float T2 = head_exact_bound(P, G, qc, keys, s_head, s_hgb, s_hn, s_hcn, h, eps, reinterpret_cast<unsigned char*>(rows), qrot, part, hist, q, tid, cost_of);
+                    if (T2 < T_ub) {
+                        m_dead = 0ull;
+                        if (tid == 0) { s_need = h; s_flag = 0u; }
+                        __syncthreads();
+                        classify(T2);
+                        dbg_tub = __float_as_uint(T2);
                     }
                 }
-                __syncthreads();
                 const bool zone_scored = s_flag != 0u || P.exact_members != 0;
                 if (zone_scored) { // (uniform; without diagnostics only when a boundary-zone list is alive) the dead zone lists too
                     for (uint32_t u = 0; u < nown && tid < n; ++u) {

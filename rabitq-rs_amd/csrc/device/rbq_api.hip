@@ -169,6 +169,7 @@ struct Replica {
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
+    bool head_exact = true;  // lazy selection: a bound of the k-th distance from real estimates of the nearest list's first vectors
     bool lazy_fault_inject = false; // TEST ONLY: makes the lazy selection wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     bool profile_counters = true; // an open profile keeps the traffic counters (option profile_counters = 0: stage timings only —
@@ -430,7 +431,7 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
     ix->dim = src->dim; ix->D = src->D; ix->Dc = src->Dc; ix->metric = src->metric; ix->rotator = src->rotator; ix->ex_bits = src->ex_bits;
     ix->n_vectors = src->n_vectors; ix->n_lists = src->n_lists; ix->n_blocks = src->n_blocks; ix->trunc = src->trunc; ix->fac = src->fac;
     ix->cnorm2_max = src->cnorm2_max; ix->h_list_n = src->h_list_n; ix->nblk_desc_prefix = src->nblk_desc_prefix;
-    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select; ix->profile_counters = src->profile_counters;
+    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select; ix->profile_counters = src->profile_counters; ix->head_exact = src->head_exact;
     for (size_t i = 0; i < sizeof(ix->arrays) / sizeof(ix->arrays[0]); ++i) {
         const Arr* s = src->arrays[i];
         Arr* d = ix->arrays[i];
@@ -1072,6 +1073,9 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     sp.lazy = (ix->lazy_select && !d_filter && !ix->no_block_bound) ? 1 : 0;
     sp.exact_members = d_diag ? 1 : 0;
     sp.fault_dead_all = ix->lazy_fault_inject ? 1 : 0;
+    sp.lut = (const uint8_t*)w->lut.p; sp.blocks = (const uint8_t*)ix->blocks.p; sp.ex_codes = (const uint8_t*)ix->ex.p;
+    sp.f_add_ex = (const float*)ix->fadd_ex.p; sp.f_rescale_ex = (const float*)ix->fres_ex.p; sp.Dc = Dc;
+    sp.head_exact = ix->head_exact ? 1 : 0;
     if (ix->exact_rank || big_nprobe) {
         uint64_t* kw = nullptr;
         if (big_nprobe) {
@@ -1749,6 +1753,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_subbatch")) ix->host_subbatch = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
         else if (!std::strcmp(name, "lazy_fault_inject")) ix->lazy_fault_inject = value != 0;
+        else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");

@@ -205,35 +205,7 @@ struct LdsHeap {
     }
 };
 
-// ---- ex-code refine: sum_t code[16t+gl] * q[16t+gl] for one 16-lane group, AVX-512 lane order --------------
-// (ip_packed_ex{2,6}_f32, src/simd.rs:1835-1915: one fused multiply-add per 16-dim step per lane, t ascending,
-// then the _mm512_reduce_add_ps halving tree.)  Units are walked in a runtime loop (next unit prefetched),
-// the CPU codes of a unit are decoded from 4 registers with compile-time shifts.  `sq` is the zero-padded
-// rotated query (ex_qlen floats): padded code slots are 0 and 0*q + s == s exactly.
-template <int EX>
-__device__ __forceinline__ float ex_dot_units(const uint8_t* __restrict__ ex, const float* sq, uint32_t gl, uint32_t nunits) {
-    constexpr int CPU = 128 / EX;
-    constexpr uint32_t mask = (1u << EX) - 1u;
-    const uint4* p = reinterpret_cast<const uint4*>(ex) + gl;
-    float sacc = 0.0f;
-    uint4 cur = p[0];
-#pragma unroll 1
-    for (uint32_t j = 0; j < nunits; ++j) {
-        const uint4 nxt = p[(j + 1 < nunits ? j + 1 : j) * 16];
-        const uint32_t w[5] = {cur.x, cur.y, cur.z, cur.w, 0u};
-        const float* qj = sq + (size_t)j * CPU * 16 + gl;
-#pragma unroll
-        for (int k = 0; k < CPU; ++k) {
-            const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
-            uint32_t code;
-            if (sh + EX <= 32) code = (w[idx] >> sh) & mask;
-            else code = ((w[idx] >> sh) | (w[idx + 1] << (32 - sh))) & mask;
-            sacc = fmaf((float)code, qj[16 * k], sacc);
-        }
-        cur = nxt;
-    }
-    return sacc;
-}
+// (ex_dot_units<EX> and group16_reduce: kernels.hpp — k_select_mfma evaluates head vectors with them too)
 // Same arithmetic with all units of a vector resident in registers (nunits <= kExRegUnits), so that the units
 // of the NEXT survivor can be in flight while this one is evaluated (heavy tiles: hundreds of survivors).
 constexpr int kExRegUnits = 4;
@@ -326,13 +298,6 @@ __device__ __forceinline__ void ex_dot_pair_units(const uint4* __restrict__ p0, 
         c0v = n0v; c1v = n1v;
     }
     s0 = acc.x; s1 = acc.y;
-}
-__device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_add_ps halving tree
-    sacc = sacc + __shfl_xor(sacc, 8, 16);
-    sacc = sacc + __shfl_xor(sacc, 4, 16);
-    sacc = sacc + __shfl_xor(sacc, 2, 16);
-    sacc = sacc + __shfl_xor(sacc, 1, 16);
-    return sacc;
 }
 
 // ---- the same BinaryHeap held in the replay wave's registers ------------------------------------------------

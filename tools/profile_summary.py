@@ -103,3 +103,18 @@ for k, c in pmc("sq").items():
     g = lambda n: statistics.median(c[n]) if n in c else float("nan")  # noqa: E731
     print(f"| `{k}` | {len(c.get('SQ_INSTS_VALU', []))} | {g('SQ_INSTS_VALU') / 1e6:.2f} M | {g('SQ_INSTS_LDS') / 1e6:.2f} M | "
           f"{g('SQ_INSTS_SALU') / 1e6:.2f} M | {g('SQ_INSTS_VMEM_RD') / 1e6:.2f} M | {g('SQ_WAVE_CYCLES') / 1e6:.1f} M | {g('SQ_BUSY_CYCLES') / 1e6:.1f} M |")
+
+w = pmc("sqwait")
+if w:
+    print("\n## Where the resident waves' cycles go (`--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS`, `--streams 1`)\n")
+    print("Quad-cycles, median per launch.  WAIT_ANY = wave parked (s_waitcnt / barrier); WAIT_INST_ANY = issue stall; ACTIVE_INST_ANY = issuing; "
+          "the three add up to about WAVE_CYCLES (MI355X_MICROARCH.md).\n")
+    print("| kernel | launches | wave cycles | parked (WAIT_ANY) | issue-stalled | issuing | LDS issue stall | LDS active |\n|---|---|---|---|---|---|---|---|")
+    for k, c in w.items():
+        if not any(t in k for t in ("k_scan", "k_select", "k_rank", "k_prep")):
+            continue
+        g = lambda n: statistics.median(c[n]) if n in c else float("nan")  # noqa: E731
+        wc = g("SQ_WAVE_CYCLES")
+        pct = lambda n: f"{g(n) / 1e6:.1f} M ({100 * g(n) / wc:.0f} %)" if wc == wc and wc > 0 else "n/a"  # noqa: E731
+        print(f"| `{k}` | {len(c.get('SQ_WAVE_CYCLES', []))} | {wc / 1e6:.1f} M | {pct('SQ_WAIT_ANY')} | {pct('SQ_WAIT_INST_ANY')} | {pct('SQ_ACTIVE_INST_ANY')} | "
+              f"{pct('SQ_WAIT_INST_LDS')} | {pct('SQ_ACTIVE_INST_LDS')} |")
