@@ -130,8 +130,11 @@ constexpr int kQueueCap = kTileBlocks - 1 + kWindow <= 512 ? 512 : 1024; // live
 #ifndef RBQ_SCAN_NB_MAXDIM
 #define RBQ_SCAN_NB_MAXDIM 0
 #endif
-__host__ __device__ constexpr int scan_nb(uint32_t DT) { return (DT != 0 && DT <= RBQ_SCAN_NB_MAXDIM) ? 2 : 1; }
-static_assert(2 * kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
+#ifndef RBQ_SCAN_NB
+#define RBQ_SCAN_NB 2
+#endif
+__host__ __device__ constexpr int scan_nb(uint32_t DT) { return (DT != 0 && DT <= RBQ_SCAN_NB_MAXDIM) ? RBQ_SCAN_NB : 1; }
+static_assert(RBQ_SCAN_NB * kTileBlocks - 1 + kWindow <= kQueueCap, "live queue too small");
 constexpr uint32_t kTopKRegMax = 256;             // largest top_k that lives in the replay wave's registers
 constexpr uint32_t kNprobeMax = 8192;             // largest nprobe of the MFMA-shortlist selector (2 x nprobe u64 keys in LDS); above it the
                                                   // exact all-pairs ranking with its key window in global memory serves the call
