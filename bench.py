@@ -350,6 +350,11 @@ def main():
         if rank == 0 and (a.device_build or a.n > 2_000_000):
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
+    def mark(msg):
+        """one stderr line per leg of the run (rank 0): if a run dies, its log says where"""
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] phase: {msg}", file=sys.stderr, flush=True)
+
     mix = Mixture(torch, dev, a.dim, a.nlist, a.dataset, a.metric == 1)
     NB = max(1, a.nbatches)
     nres = a.batch * a.top_k
@@ -746,6 +751,7 @@ def main():
         print(json.dumps(out))
         return
 
+    mark("timed regions + counter pass")
     ns = max(1, a.streams)
     dts, own_dts, prof = run_measured(idx, q_all, a.nprobe, a.steps, a.warmup, ns, gather=True, min_seconds=a.min_seconds)
     dt = statistics.median(dts)  # the median K-step region (each one bracketed by barrier + synchronize, max over ranks)
@@ -759,6 +765,7 @@ def main():
         per_rank = [float(v) for v in t.tolist()]
         rccl_world = dist.get_world_size() if dist.get_backend() == "nccl" else None
 
+    mark("results of every batch (recall)")
     # results of every batch (one stream): recall over ALL of them, and the same ids whatever the stream
     ids_all = search_ids(idx, q_all, a.nprobe)
     gtn = gt.cpu().numpy().reshape(NB, a.batch, a.top_k)
@@ -767,6 +774,7 @@ def main():
 
     # the roofline figure: the same kernel with the block-level bound switched off streams EVERY probed block — the
     # algorithmic bytes are really moved (results identical, only the work changes); one stream, k_scan alone on the chip
+    mark("roofline leg (block bound off) + per-stage pass")
     roofline = None
     serial = None
     if rank == 0:
@@ -810,6 +818,7 @@ def main():
 
     # the host-buffer entry point (rbq_search_batch: H2D of the queries, the four kernels, D2H of the results) — what a
     # CPU-side caller such as the Rust shim binds (src/ivf.rs:1743-1752)
+    mark("host entry legs")
     pcie = None
     host_call = None
     if extras:
@@ -930,6 +939,7 @@ def main():
                         "approach the device-resident rate.  `value` is the device-resident rate; these are the rates a host-side "
                         "caller sees.")
 
+    mark("latency leg")
     latency = latency_leg() if (extras and not a.no_latency) else None
     if host_call is not None and latency is not None and "64" in latency:
         host_call["model_us_per_call"] = a.batch / (value / world) * 1e6 + latency["64"]["p50_us"]
@@ -937,6 +947,7 @@ def main():
     # Self-check for indexes no CPU oracle run can cover (device-built: cfg5 at 100 M vectors): the first 256 queries again
     # with every shortcut switched off — canonical all-pairs ranking instead of the MFMA shortlist, BinaryHeap emulation from
     # the first candidate, no block-level bound — must give the same bits.
+    mark("self check")
     self_check = None
     if extras:
         nsc = min(256, a.batch)
@@ -962,6 +973,7 @@ def main():
                                  "first candidate) and block_bound=0 (every probed block scanned)"}
 
     # second data set of the pair (rank 0, headline workload only): SURVEY 8d's isotropic mixture
+    mark("second data set")
     datasets = {a.dataset: {"recall_at_k": recall, "queries_per_s": value / world, "nprobe": a.nprobe,
                             "block_skip_frac": pruned["block_skip_frac"], "role": "headline"}}
     if extras and is_headline:
@@ -999,6 +1011,7 @@ def main():
     # wait.  Per stage: the kernel instantiation this call shape launches and what it occupies (rbq_debug_stage_resources: live,
     # from the code object), its duration alone and under overlap (HIP events on the dispatch packets); resident wave-time per
     # step against the wave slots the chip offers in one step time.
+    mark("regime + sensitivity")
     regime = None
     if rank == 0:
         try:
@@ -1118,6 +1131,7 @@ def main():
         "encoder": encoder,
         "rank_fallbacks": int(idx.rank_fallbacks()),
         "heap_restarts": int(idx.heap_restarts()),
+        "head_exact": dict(zip(("evaluations", "guard_trips"), idx.head_exact_stats())),
         "roofline": roofline,
         "pruned": pruned,
         "regime": regime,
@@ -1129,6 +1143,7 @@ def main():
         "datasets": datasets,
     }
 
+    mark("cpu baseline")
     if rank == 0 and world == 1 and not a.no_cpu and built is not None:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle  # CPU oracle: checker + reported baseline only

@@ -258,6 +258,10 @@ int rbq_debug_stage_resources(rbq_index* idx, uint64_t nq, uint32_t top_k, uint3
  * hipMemcpyPeer: the path taken when the runtime refuses the peer copy, or for every replica copy when RBQ_FORCE_NO_PEER=1 is in
  * the environment (test switch: the only way the path can run on a one-GPU box). Diagnostic. */
 uint64_t rbq_debug_bounce_copies(void);
+/* Exact head evaluation of the lazy probe selection (since creation): queries for which it ran / times its geometry guard tripped
+ * (must stay 0). Diagnostic. */
+uint64_t rbq_debug_head_exact_evaluations(const rbq_index* idx);
+uint64_t rbq_debug_head_exact_guard_trips(const rbq_index* idx);
 /* Number of queries (since creation) that met two bit-identical distances in their top-k and were therefore
  * re-run inside the scan kernel with the exact BinaryHeap emulation (src/ivf.rs:2078-2105 pushes into a
  * std BinaryHeap, whose tie behaviour depends on its layout). Diagnostic. */

@@ -98,6 +98,7 @@ struct SelectParams {
     const uint8_t* ex_codes;
     const float *f_add_ex, *f_rescale_ex;
     uint32_t Dc;
+    uint32_t n_blocks;            // blocks of the index (the exact head evaluation checks its geometry against it)
     int head_exact;               // 0: Cauchy-Schwarz bound only (round 3)
     int fault_dead_all;           // TEST ONLY (debug option lazy_fault_inject, default 0): T_ub := -inf — every list behind the head is
                                   // declared dead whatever its bounds say: a deliberately WRONG selection, so that the

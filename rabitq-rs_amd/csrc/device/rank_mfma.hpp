@@ -649,6 +649,13 @@ __device__ __forceinline__ float head_exact_bound(const SelectParams& P, const S
     const uint32_t gb = s_hgb[r0], nvec = s_hn[r0];
     const uint32_t nv = nvec < G.hx_nv ? nvec : G.hx_nv;
     if (nv < top_k || top_k == 0 || !hx_tame(g_add) || !hx_tame(ge_hi)) return INFINITY; // (uniform)
+    // geometry guard: the blocks this pass reads must lie inside the index (a trip is counted and the pass is skipped — it is an
+    // optimisation, never needed for correctness)
+    if (r0 >= h || (uint64_t)gb + ((nv + 31u) >> 5) > (uint64_t)P.n_blocks) {
+        if (tid == 0 && P.fallback_count) atomicAdd(P.fallback_count + 2, 1u);
+        return INFINITY;
+    }
+    if (tid == 0 && P.fallback_count) atomicAdd(P.fallback_count + 3, 1u);
     uint8_t* lutL = scratch;
     float* sq = reinterpret_cast<float*>(scratch + (size_t)Dc * 4);
     const uint32_t qlen = ex_bits ? ex_qlen(D, ex_bits) : 0u;
@@ -728,7 +735,8 @@ __device__ __forceinline__ float head_exact_bound(const SelectParams& P, const S
         const uint32_t nunits = ex_w4(D, ex_bits);
         const size_t exb = ex_bytes_dev(D, ex_bits);
         for (uint32_t j = grp; j < R; j += kThreads / 16) {
-            const uint32_t v = hist[j];
+            uint32_t v = hist[j];
+            if (v >= nv) { if (gl == 0 && P.fallback_count) atomicAdd(P.fallback_count + 2, 1u); v = 0; } // (guard: cannot happen; never read out of the list)
             const uint32_t slot = (gb + (v >> 5)) * 32u + (v & 31u);
             const uint8_t* ex = P.ex_codes + (size_t)slot * exb;
             float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, sq, gl, nunits) : ex_dot_units<2>(ex, sq, gl, nunits);
@@ -1246,7 +1254,12 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 // T' := the k-th smallest U_v.  Same claim as for T_ub (any k vectors the reference visits before the dead
                 // lists will do): each of them, if it sees a threshold > T' >= lb_v, is evaluated and pushed with a distance
                 // <= T'.  Lists are then classified again against min(T_ub, T').
-                if (G.hx_nv && P.head_exact && s_need - h > kHxTrigger) { // (uniform: s_need is final behind classify's barrier)
+                // (the count is read by every thread and fenced by a barrier BEFORE anyone may change it again: the zone step
+                // below adds to s_need, and a thread that read the raised count would take this branch — and its barriers — alone.
+                // That race was a rare "memory access fault" in the first builds of this step.)
+                const uint32_t need1 = s_need;
+                __syncthreads();
+                if (G.hx_nv && P.head_exact && need1 - h > kHxTrigger) { // (uniform)
                     const float T2 = head_exact_bound(P, G, qc, keys, s_head, s_hgb, s_hn, s_hcn, h, eps, reinterpret_cast<unsigned char*>(rows), qrot, part, hist, q, tid, cost_of);
                     if (T2 < T_ub) {
                         m_dead = 0ull;

@@ -368,8 +368,8 @@ int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
                                   (const float*)ix->fres_ex.p, (const float*)ix->centroids.p, (const BlockSummary*)ix->bsum.p,
                                   (const uint32_t*)ix->list_gb0.p, (const uint32_t*)ix->list_n.p, nlist, D, ix->Dc, ix->ex_bits,
                                   (BlockSummaryEx*)ix->bsumx.p, (BlockSummary*)ix->lsum.p, 0));
-    if ((rc = alloc_arr(ix->fallbacks, 8))) return rc;   // [0] rank fallbacks, [1] heap restarts
-    HIP_TRY(hipMemset(ix->fallbacks.p, 0, 8));
+    if ((rc = alloc_arr(ix->fallbacks, 16))) return rc;   // [0] rank fallbacks, [1] heap restarts, [2] exact-head guard trips, [3] exact-head evaluations
+    HIP_TRY(hipMemset(ix->fallbacks.p, 0, 16));
     if ((rc = alloc_arr(ix->prof, (size_t)kProfStripes * kProfSlots * 8))) return rc;
     HIP_TRY(hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8));
     const char* e = std::getenv("RBQ_EXACT_RANK");
@@ -441,7 +441,7 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
         if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, std::string("replicating the index: ") + hipGetErrorString(e)); }
         d->bytes = s->bytes;
     }
-    hipError_t e = hipMemset(ix->fallbacks.p, 0, 8);
+    hipError_t e = hipMemset(ix->fallbacks.p, 0, 16);
     if (e == hipSuccess) e = hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8);
     if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, hipGetErrorString(e)); }
     *out = ix;
@@ -1076,6 +1076,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     sp.lut = (const uint8_t*)w->lut.p; sp.blocks = (const uint8_t*)ix->blocks.p; sp.ex_codes = (const uint8_t*)ix->ex.p;
     sp.f_add_ex = (const float*)ix->fadd_ex.p; sp.f_rescale_ex = (const float*)ix->fres_ex.p; sp.Dc = Dc;
     sp.head_exact = ix->head_exact ? 1 : 0;
+    sp.n_blocks = (uint32_t)ix->n_blocks;
     if (ix->exact_rank || big_nprobe) {
         uint64_t* kw = nullptr;
         if (big_nprobe) {
@@ -1775,6 +1776,8 @@ static uint64_t read_counter(const rbq_index* h, int slot) {
     return tot;
 }
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* h) { return read_counter(h, 0); }
+uint64_t rbq_debug_head_exact_guard_trips(const rbq_index* h) { return read_counter(h, 2); }
+uint64_t rbq_debug_head_exact_evaluations(const rbq_index* h) { return read_counter(h, 3); }
 // Which kernel instantiation each of the four stages launches for a call of this shape, and what it occupies.
 // out[stage][6] = workgroups, threads per workgroup, VGPRs per lane, LDS bytes per workgroup (static + dynamic), scratch bytes per
 // lane, 0; stages in the order prep, rank, select, scan.  Nothing is launched.

@@ -66,6 +66,9 @@ def lib():
         L.rbq_debug_rank_fallbacks.argtypes = [vp]
         L.rbq_debug_stage_resources.restype = C.c_int
         L.rbq_debug_stage_resources.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+        for n_ in ("rbq_debug_head_exact_evaluations", "rbq_debug_head_exact_guard_trips"):
+            getattr(L, n_).restype = C.c_uint64
+            getattr(L, n_).argtypes = [vp]
         L.rbq_debug_bounce_copies.restype = C.c_uint64
         L.rbq_debug_bounce_copies.argtypes = []
         L.rbq_index_build_device.restype = C.c_int
@@ -312,6 +315,10 @@ class IvfRabitqIndex:
         _check(lib().rbq_debug_stage_resources(self._h, nq, top_k, nprobe, out.ctypes.data))
         return {s: {"workgroups": int(o[0]), "threads": int(o[1]), "vgprs": int(o[2]), "lds_bytes": int(o[3]), "scratch_bytes": int(o[4])}
                 for s, o in zip(("prep", "rank", "select", "scan"), out)}
+
+    def head_exact_stats(self):
+        """(queries whose probe selection ran the exact head evaluation, guard trips — must be 0)"""
+        return int(lib().rbq_debug_head_exact_evaluations(self._h)), int(lib().rbq_debug_head_exact_guard_trips(self._h))
 
     def rank_fallbacks(self):
         return lib().rbq_debug_rank_fallbacks(self._h)
