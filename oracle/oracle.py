@@ -48,6 +48,14 @@ def lib():
         for n in ("ref_ip_packed_ex2", "ref_ip_packed_ex6"):
             getattr(L, n).restype = C.c_float
             getattr(L, n).argtypes = [f32p, u8p, C.c_size_t]
+        L.ref_heap_trace.restype = C.c_int
+        L.ref_heap_trace.argtypes = [f32p, vp, C.c_size_t, C.c_uint32, vp, f32p, vp]
+        L.ref_have_avx512.restype = C.c_int
+        for n in ("ref_reduce_add_16", "ref_reduce_add_16_avx512"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [f32p]
+        L.ref_ip_packed_ex_avx512.restype = C.c_float
+        L.ref_ip_packed_ex_avx512.argtypes = [f32p, u8p, C.c_size_t, C.c_uint32]
         L.ref_ex_dot.restype = C.c_float
         L.ref_ex_dot.argtypes = [f32p, u8p, C.c_size_t, C.c_uint32]
         L.ref_select_probes.restype = C.c_size_t

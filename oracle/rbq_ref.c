@@ -27,7 +27,10 @@
  * into_sorted_vec sift order; toolchain pinned nightly-2025-12-13 by
  * rust-toolchain.toml:2) and `core::arch::x86_64::_mm512_reduce_add_ps`
  * (stdarch: 16->8->4->2->1 halving tree).  They only matter for exact ties and
- * for the last-bit rounding of the ex-code dot product.
+ * for the last-bit rounding of the ex-code dot product.  Since round 4 both are
+ * pinned by a second definition (tests/test_oracle_kat.py): the reduce tree and
+ * the 16-lane FMA order against real AVX-512 instructions (gcc's own
+ * _mm512_reduce_add_ps), the heap's push / pop order against CPython's heapq.
  */
 #include <math.h>
 #include <stdint.h>
@@ -503,6 +506,44 @@ float ref_ip_packed_ex6(const float* q, const uint8_t* code, size_t D) {
     return reduce_add_16(s);
 }
 
+/* The same dot products on REAL AVX-512 instructions: 16-lane _mm512_fmadd_ps per 16-dim step and the compiler's own     */
+/* _mm512_reduce_add_ps (gcc avx512fintrin.h: extract 256 + add, extract 128 + add, shuffle {2,3,0,1} + add, lane 0 + lane 1 */
+/* — Intel's sequence, the halving tree above).  The codes are unpacked by the scalar emulation's own expressions.  They pin */
+/* reduce_add_16 and the lane order to a second definition (round-3 VERDICT, weak 1).  Return 0 when the host lacks AVX-512. */
+__attribute__((target("avx512f")))
+static float ip_packed_ex_avx512(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits) {
+    __m512 acc = _mm512_setzero_ps();
+    for (size_t t = 0; t < D / 16; ++t) {
+        float cf[16];
+        if (ex_bits == 2) {
+            uint32_t w;
+            memcpy(&w, code + t * 4, 4);
+            for (int i = 0; i < 4; ++i)
+                for (int g = 0; g < 4; ++g) cf[i + 4 * g] = (float)((w >> (8 * i + 2 * g)) & 3u);
+        } else {
+            uint64_t lo;
+            uint32_t hi;
+            memcpy(&lo, code + t * 12, 8);
+            memcpy(&hi, code + t * 12 + 8, 4);
+            for (int l = 0; l < 16; ++l) {
+                uint32_t low4 = l < 8 ? (uint32_t)((lo >> (8 * l)) & 15u) : (uint32_t)((lo >> (8 * (l - 8) + 4)) & 15u);
+                uint32_t top2 = (hi >> (8 * (l & 3) + 2 * (l >> 2))) & 3u;
+                cf[l] = (float)(low4 | (top2 << 4));
+            }
+        }
+        acc = _mm512_fmadd_ps(_mm512_loadu_ps(cf), _mm512_loadu_ps(q + t * 16), acc);
+    }
+    return _mm512_reduce_add_ps(acc);
+}
+__attribute__((target("avx512f")))
+static float reduce_add_16_avx512(const float* s) { return _mm512_reduce_add_ps(_mm512_loadu_ps(s)); }
+int ref_have_avx512(void) { return __builtin_cpu_supports("avx512f") ? 1 : 0; }
+float ref_reduce_add_16(const float* s) { return reduce_add_16(s); }
+float ref_reduce_add_16_avx512(const float* s) { return ref_have_avx512() ? reduce_add_16_avx512(s) : 0.0f; }
+float ref_ip_packed_ex_avx512(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits) {
+    return ref_have_avx512() ? ip_packed_ex_avx512(q, code, D, ex_bits) : 0.0f;
+}
+
 /* fast bodies with identical numerics (two 8-lane FMA accumulators = lanes 0-7, 8-15) */
 __attribute__((target("avx2,fma")))
 static float ip_packed_ex6_fast(const float* q, const uint8_t* code, size_t D) {
@@ -632,6 +673,28 @@ static void heap_into_sorted(heap_t* h) {
         hent t = h->d[0]; h->d[0] = h->d[end]; h->d[end] = t;
         sift_down_range(h, 0, end);
     }
+}
+
+/* The top-k bookkeeping of search_cluster_v2_batched alone (src/ivf.rs:2116-2126: push, pop while len > top_k; then            */
+/* into_sorted_vec, :1874-1878) over a given sequence of (distance, id) pushes — exported so that tests/test_oracle_kat.py can   */
+/* pin the sift order (which decides exact ties) against CPython's heapq, an independent implementation of the same published  */
+/* algorithm (push = sift up from the end; pop = move the last element to the root, sift it to the bottom, sift it back up).    */
+int ref_heap_trace(const float* dist, const uint64_t* ids, size_t n, uint32_t top_k, uint64_t* out_ids, float* out_dist,
+                   uint32_t* out_len) {
+    heap_t heap;
+    heap.d = (hent*)malloc(((size_t)top_k + 2) * sizeof(hent));
+    heap.len = 0;
+    if (!heap.d) return RBQ_IO;
+    for (size_t i = 0; i < n; ++i) {
+        hent e; e.id = ids[i]; e.distance = dist[i];
+        heap_push(&heap, e);
+        if (heap.len > top_k) heap_pop(&heap);
+    }
+    heap_into_sorted(&heap);
+    for (size_t i = 0; i < heap.len; ++i) { out_ids[i] = heap.d[i].id; out_dist[i] = heap.d[i].distance; }
+    *out_len = (uint32_t)heap.len;
+    free(heap.d);
+    return RBQ_OK;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -40,6 +40,12 @@ void     ref_compute_batch_distances(const uint16_t* accu, float delta, float su
 float    ref_ip_packed_ex2(const float* q, const uint8_t* code, size_t D);
 float    ref_ip_packed_ex6(const float* q, const uint8_t* code, size_t D);
 float    ref_ex_dot(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits);
+int      ref_heap_trace(const float* dist, const uint64_t* ids, size_t n, uint32_t top_k, uint64_t* out_ids, float* out_dist,
+                        uint32_t* out_len);
+int      ref_have_avx512(void);
+float    ref_reduce_add_16(const float* s);                 /* the halving tree the oracle uses for _mm512_reduce_add_ps */
+float    ref_reduce_add_16_avx512(const float* s);          /* the compiler's own _mm512_reduce_add_ps (0 without AVX-512) */
+float    ref_ip_packed_ex_avx512(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits); /* real 16-lane FMA + reduce */
 size_t   ref_select_probes(const rbq_header* h, const rbq_list_view* lists, const float* rq,
                            uint32_t nprobe_in, uint32_t* out_cids);
 int      ref_search(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,

@@ -149,6 +149,55 @@ struct Arr { // one device array of a replica (size kept for cloning)
     size_t bytes = 0;
 };
 
+// Persistent staging helpers of a replica (rbq_search_batch with PAGEABLE queries).  The queries of a call must be copied once
+// into page-locked memory before the GPU can read them; one thread copies 3.9 MB (1024 x 960 f32) in ~165 us — more than half of the
+// ~280 us the same call takes from page-locked buffers.  The sub-batches of a call have their own lanes and staging buffers, so
+// their copies are independent: the caller copies sub-batch 0 (and launches it at once), the helpers copy the others meanwhile.
+// Started on the first pageable call, joined when the replica is freed; a helper that has just finished polls ~100 us for the
+// next job before it blocks (callers that issue calls back to back find the helpers hot).
+struct StageHelpers {
+    static constexpr int kThreads = 3;
+    struct Job { void* dst; const void* src; size_t bytes; std::atomic<int>* done; };
+    std::thread th[kThreads];
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    std::atomic<uint32_t> pending{0};
+    bool stop = false;
+    void run() {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                job = jobs.front();
+                jobs.pop_front();
+            }
+            std::memcpy(job.dst, job.src, job.bytes);
+            job.done->store(1, std::memory_order_release);
+            pending.fetch_sub(1, std::memory_order_release);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (pending.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(100)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+    }
+    void start() { for (auto& t : th) t = std::thread([this] { run(); }); }
+    void post(const Job& j) {
+        pending.fetch_add(1, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(mu); jobs.push_back(j); }
+        cv.notify_one();
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) if (t.joinable()) t.join();
+    }
+};
+
 // One device-resident copy of the index.
 struct Replica {
     int device = 0;
@@ -167,6 +216,8 @@ struct Replica {
     bool rerank = false;
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
+    bool host_stage_helpers = true; // rbq_search_batch: pageable queries of a call's later sub-batches are staged by helper threads
+    std::unique_ptr<StageHelpers> stagers; // (created on the first pageable call, under `mu`)
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     bool head_exact = true;  // lazy selection: a bound of the k-th distance from real estimates of the nearest list's first vectors
@@ -267,6 +318,7 @@ int upload_arr(Arr& a, const void* src, size_t bytes) {
 
 void free_replica(Replica* ix) {
     if (!ix) return;
+    if (ix->stagers) ix->stagers->shutdown();
     DeviceGuard g(ix->device);
     (void)hipDeviceSynchronize();
     for (Arr* a : ix->arrays)
@@ -1192,6 +1244,30 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         tick(td, t_out);
         return RBQ_OK;
     };
+    // pageable queries inside the zero-copy window: every sub-batch has its own lane (nsub <= nlanes), so the helpers can stage
+    // sub-batches 1.. into their lanes' pinned buffers while this thread stages and launches sub-batch 0
+    constexpr uint64_t kMaxHelped = 8;
+    std::atomic<int> staged[kMaxHelped];
+    uint64_t n_helped = 0; // sub-batches 1 .. n_helped are staged by helpers
+    struct WaitHelpers { std::atomic<int>* f; uint64_t& n; // (no job may outlive this frame: it writes the flags)
+        ~WaitHelpers() { for (uint64_t j = 1; j <= n; ++j) while (!f[j].load(std::memory_order_acquire)) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        } } } wait_helpers{staged, n_helped};
+    if (zero_copy && !in_pinned && ix->host_stage_helpers && nsub >= 2 && nsub <= nlanes && nsub <= kMaxHelped && nq * query_dim * 4 >= (512u << 10)) {
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            if (!ix->stagers) { ix->stagers.reset(new StageHelpers()); ix->stagers->start(); }
+        }
+        for (uint64_t j = 1; j < nsub; ++j) {
+            Workspace* wj = lanes[j];
+            if ((rc = wj->h_in.ensure(plan[j].second * query_dim * 4))) return rc; // (jobs posted so far are awaited by wait_helpers)
+            staged[j].store(0, std::memory_order_relaxed);
+            ix->stagers->post({wj->h_in.p, queries + plan[j].first * query_dim, (size_t)(plan[j].second * query_dim * 4), &staged[j]});
+            n_helped = j;
+        }
+    }
     for (uint64_t j = 0; j < nsub; ++j) {
         Workspace* w = lanes[j % nlanes];
         if (j >= nlanes && (rc = deliver(w, j - nlanes))) return rc;
@@ -1205,8 +1281,16 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         if (c_queries) {
             d_q = c_queries + q0 * query_dim;
         } else if (zero_copy && !in_pinned) { // pageable: one host copy into the lane's pinned buffer, read from there
-            if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
-            std::memcpy(w->h_in.p, src, n * query_dim * 4);
+            if (j >= 1 && j <= n_helped) { // staged by a helper: wait for its copy
+                while (!staged[j].load(std::memory_order_acquire)) {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+            } else {
+                if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
+                std::memcpy(w->h_in.p, src, n * query_dim * 4);
+            }
             float* hp = nullptr;
             HIP_TRY(hipHostGetDevicePointer((void**)&hp, w->h_in.p, 0));
             d_q = hp;
@@ -1756,6 +1840,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "lazy_fault_inject")) ix->lazy_fault_inject = value != 0;
         else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
+        else if (!std::strcmp(name, "host_stage_helpers")) ix->host_stage_helpers = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
             ix->rerank = value != 0;

@@ -221,8 +221,8 @@ def test_bound_violations_audit_detects_a_loosened_bound():
     idx.close()
 
 
-@pytest.mark.parametrize("zero_copy", [0, 1])
-def test_host_entry_paths_give_identical_results(zero_copy):
+@pytest.mark.parametrize("zero_copy,helpers", [(0, 0), (1, 0), (1, 1)])
+def test_host_entry_paths_give_identical_results(zero_copy, helpers):
     """rbq_search_batch with the round-4 host path (queries read from page-locked memory in place, tapered sub-batches):
     pageable and page-locked buffers, ragged call sizes
     around every boundary of the sub-batch plan, with diagnostics and a filter — always the device entry's bits."""
@@ -230,6 +230,7 @@ def test_host_entry_paths_give_identical_results(zero_copy):
     data, built = build_index(n=20000, dim=128, nlist=96, total_bits=7, seed=471)
     idx = rq.IvfRabitqIndex.from_built(built)
     idx.set_option("host_zero_copy", zero_copy)
+    idx.set_option("host_stage_helpers", helpers)  # pageable queries of a call's later sub-batches staged by helper threads
     lib = rq.index.lib()
     dev = torch.device("cuda", 0)
     top_k, nprobe = 10, 12

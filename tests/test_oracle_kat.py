@@ -350,3 +350,98 @@ def test_probe_selection_is_the_full_sort_prefix():
                 got = oracle.select_probes(built, rq, nprobe)
                 want = order[:min(max(nprobe, 1), 37)]
                 assert np.array_equal(got, want.astype(np.uint32)), (metric, qi, nprobe)
+
+
+def test_reduce_tree_and_lane_order_against_real_avx512():
+    """Round-3 VERDICT (weak 1): the oracle's `_mm512_reduce_add_ps` tree and 16-lane FMA order were restated from memory.  On a
+    host with AVX-512 (this container and the GPU box's EPYC both have it) they are checked bit for bit against the real thing:
+    gcc's own `_mm512_reduce_add_ps` (avx512fintrin.h: the 16 -> 8 -> 4 -> 2 -> 1 halving sequence Intel documents, which is also
+    what LLVM emits for the reassociating vector reduction Rust's stdarch maps the intrinsic to) and `_mm512_fmadd_ps` over the
+    packed codes, on inputs whose partial sums span 12 orders of magnitude — any other association shows in the last bits."""
+    L = oracle.lib()
+    if not L.ref_have_avx512():
+        pytest.skip("host without AVX-512")
+    rng = np.random.default_rng(7)
+    differs_from_sequential = 0
+    for _ in range(2000):
+        s = (rng.standard_normal(16) * 10.0 ** rng.integers(-6, 7, 16)).astype(np.float32)
+        a, b = L.ref_reduce_add_16(s.ctypes.data), L.ref_reduce_add_16_avx512(s.ctypes.data)
+        assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32)
+        seq = np.float32(0)
+        for v in s:
+            seq = np.float32(seq + v)
+        differs_from_sequential += int(np.float32(a).view(np.uint32) != seq.view(np.uint32))
+    assert differs_from_sequential > 500  # the inputs do distinguish summation orders
+    for ex_bits, D in ((6, 960), (6, 64), (2, 960), (2, 128), (6, 2048)):
+        for _ in range(40):
+            q = (rng.standard_normal(D) * 10.0 ** rng.integers(-3, 4, D)).astype(np.float32)
+            code = rng.integers(0, 256, D * ex_bits // 8, dtype=np.uint8)
+            a = L.ref_ex_dot(q.ctypes.data, code.ctypes.data, D, ex_bits)
+            b = L.ref_ip_packed_ex_avx512(q.ctypes.data, code.ctypes.data, D, ex_bits)
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (ex_bits, D)
+
+
+def test_heap_sift_order_against_cpython_heapq():
+    """Round-3 VERDICT (weak 1): the oracle's BinaryHeap sift order decides which of several bit-identical distances stays in
+    the top-k and in what order they come out.  Rust's `BinaryHeap::push` / `pop` (alloc::collections::binary_heap: sift_up from
+    the end; swap the last element into the root, `sift_down_to_bottom`, `sift_up`) is the algorithm CPython's `heapq`
+    implements (`_siftdown` / `_siftup`: "bubble the smaller child up until hitting a leaf, then sift the item back up") with the
+    same tie rules under a reversed comparison: move up only past a STRICTLY smaller parent, prefer the right child unless the left
+    one is strictly better.  The oracle's push / pop-while-over-k sequence must leave exactly heapq's array, pop for pop, on
+    tie-heavy input; `into_sorted_vec` (`sift_down_range`) is then checked against a direct Python restatement."""
+    import heapq
+
+    class Ent:  # ordered by distance only (HeapEntry: Ord on distance via total_cmp, src/ivf.rs:904-931); reversed: heapq is a min-heap
+        __slots__ = ("d", "i")
+
+        def __init__(self, d, i):
+            self.d, self.i = d, i
+
+        def __lt__(self, o):
+            return self.d > o.d
+
+    def into_sorted(a):  # BinaryHeap::into_sorted_vec on the max-heap array `a` (list of Ent)
+        def le(x, y):
+            return x.d <= y.d
+        end = len(a)
+        while end > 1:
+            end -= 1
+            a[0], a[end] = a[end], a[0]
+            pos, e = 0, a[0]
+            child = 1
+            while end >= 2 and child <= end - 2:
+                child += 1 if le(a[child], a[child + 1]) else 0
+                if not (e.d < a[child].d):
+                    break
+                a[pos] = a[child]
+                pos = child
+                child = 2 * pos + 1
+            else:
+                if child == end - 1 and e.d < a[child].d:
+                    a[pos] = a[child]
+                    pos = child
+            a[pos] = e
+        return a
+
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        n = int(rng.integers(1, 400))
+        top_k = int(rng.choice([1, 2, 3, 5, 10, 17, 64, 100]))
+        levels = int(rng.choice([2, 3, 5, 20, 1000]))           # few distinct distances: ties everywhere
+        dist = rng.integers(0, levels, n).astype(np.float32) * np.float32(0.25)
+        ids = np.arange(n, dtype=np.uint64) + 1000
+        heap = []
+        for d, i in zip(dist.tolist(), ids.tolist()):
+            heapq.heappush(heap, Ent(d, i))
+            if len(heap) > top_k:
+                heapq.heappop(heap)
+        want = into_sorted(list(heap))
+        out_ids = np.zeros(top_k, np.uint64)
+        out_d = np.zeros(top_k, np.float32)
+        ln = C.c_uint32()
+        assert L.ref_heap_trace(dist.ctypes.data, ids.ctypes.data, n, top_k, out_ids.ctypes.data, out_d.ctypes.data, C.byref(ln)) == 0
+        assert ln.value == len(want)
+        assert out_ids[:ln.value].tolist() == [e.i for e in want], (trial, n, top_k, levels)
+        assert out_d[:ln.value].tolist() == [e.d for e in want]
+        assert all(out_d[j] <= out_d[j + 1] for j in range(ln.value - 1))

@@ -1,5 +1,5 @@
 """Per-call time of rbq_search_batch (host buffers in and out, ONE caller thread) against the host-path switches:
-zero-copy query reads, sub-batch size x lanes.  Median / p10 of many calls (the box's host CPUs are shared:
+zero-copy query reads, staging helper threads (pageable queries), sub-batch size x lanes.  Median / p10 of many calls (the box's host CPUs are shared:
 single regions scatter), ids checked against the device entry.
 python tools/host_call_probe.py [n] [nlist]        HOST_PROBE_SHAPES="256x4,512x2" HOST_PROBE_NQ="1024,4096"
 """
@@ -76,14 +76,15 @@ def run(batch, shapes, reps):
 
     print(f"--- {batch} queries per call, {reps} calls per cell; us per call: median (p10) -> M queries/s at the median", flush=True)
     for zc in (0, 1):
-        for poll in (0,):
+        for hlp in (0, 1):
             idx.set_option("host_zero_copy", zc)
+            idx.set_option("host_stage_helpers", hlp)
             for sub, lanes in shapes:
                 idx.set_option("host_subbatch", sub)
                 idx.set_option("host_lanes", lanes)
                 mp, pp, okp = measure(True)
                 mg, pg, okg = measure(False)
-                print(f"zero_copy {zc} poll {poll} sub {sub:5d} x {lanes}: pinned {mp:7.1f} ({pp:7.1f}) -> {batch / mp:5.2f} M   "
+                print(f"zero_copy {zc} helpers {hlp} sub {sub:5d} x {lanes}: pinned {mp:7.1f} ({pp:7.1f}) -> {batch / mp:5.2f} M   "
                       f"pageable {mg:7.1f} ({pg:7.1f}) -> {batch / mg:5.2f} M   ids ok {okp} {okg}", flush=True)
     for j in range(NSETS):
         for p in pin[j]:
