@@ -1199,9 +1199,11 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         }
     }
     // page-locked queries are read by k_prep where they lie (device-side address of the caller's buffer)
-    // (measured, GIST-1M shape: 1024 queries per call 297 -> 280 us, 256: 212 -> 198 us; but one query 133 -> 147 us, and
-    // from 4096 queries per call the copy engine is faster than the waves' own PCIe reads: 678 -> 778 us — hence the window)
-    const bool zero_copy = ix->host_zero_copy && nq >= 32 && nq <= 2048;
+    // (measured, GIST-1M shape: 1024 queries per call 297 -> 280 us, 1536: 388 -> 376, 256: 212 -> 198 us; but one query 133 -> 147 us,
+    // 2048 per call 445 -> 457 and from 4096 the copy engine clearly beats the waves' own PCIe reads: 678 -> 778 us — hence the window)
+    // (pageable queries, read from the lane's pinned staging buffer: 1024 per call 381 -> 373 us, but 2048 per call 524 -> 591 us:
+    // there the staged DMA pieces overlap the host copy better than one big copy followed by in-place reads — window <= 1024)
+    const bool zero_copy = ix->host_zero_copy && nq >= 32 && nq <= (in_pinned ? 1536u : 1024u);
     const float* c_queries = nullptr;
     if (zero_copy && in_pinned && hipHostGetDevicePointer((void**)&c_queries, const_cast<float*>(queries), 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -1244,8 +1246,8 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         tick(td, t_out);
         return RBQ_OK;
     };
-    // pageable queries inside the zero-copy window: every sub-batch has its own lane (nsub <= nlanes), so the helpers can stage
-    // sub-batches 1.. into their lanes' pinned buffers while this thread stages and launches sub-batch 0
+    // pageable queries, every sub-batch on its own lane (nsub <= nlanes): the helpers stage sub-batches 1.. into their lanes' pinned
+    // buffers while this thread stages and launches sub-batch 0
     constexpr uint64_t kMaxHelped = 8;
     std::atomic<int> staged[kMaxHelped];
     uint64_t n_helped = 0; // sub-batches 1 .. n_helped are staged by helpers
@@ -1255,7 +1257,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             __builtin_ia32_pause();
 #endif
         } } } wait_helpers{staged, n_helped};
-    if (zero_copy && !in_pinned && ix->host_stage_helpers && nsub >= 2 && nsub <= nlanes && nsub <= kMaxHelped && nq * query_dim * 4 >= (512u << 10)) {
+    if (!in_pinned && ix->host_stage_helpers && nsub >= 2 && nsub <= nlanes && nsub <= kMaxHelped && nq * query_dim * 4 >= (512u << 10)) {
         {
             std::lock_guard<std::mutex> lk(ix->mu);
             if (!ix->stagers) { ix->stagers.reset(new StageHelpers()); ix->stagers->start(); }
@@ -1296,6 +1298,13 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             d_q = hp;
         } else if (in_pinned) {
             HIP_TRY(hipMemcpyAsync(w->queries.p, src, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
+        } else if (j >= 1 && j <= n_helped) { // pageable, staged by a helper: wait for its copy, one DMA
+            while (!staged[j].load(std::memory_order_acquire)) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            HIP_TRY(hipMemcpyAsync(w->queries.p, w->h_in.p, n * query_dim * 4, hipMemcpyHostToDevice, w->stream));
         } else {
             if ((rc = w->h_in.ensure(n * query_dim * 4))) return rc;
             const uint64_t piece = std::max<uint64_t>(64, (n + 3) / 4); // queries per piece

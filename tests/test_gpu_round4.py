@@ -344,3 +344,46 @@ def test_bench_gpus_4_rehearsal():
                     "--n", "100000", "--nlist", "512", "--nprobe", "16", "--streams", "4"], {"RBQ_BENCH_REHEARSAL": "1"}, timeout=1200)
     assert d["n_gpus"] == 4 and d["value"] > 0 and len(d["per_rank_queries_per_s"]) == 4 and all(v > 0 for v in d["per_rank_queries_per_s"])
     assert d["scaling"] == "weak" and d["rccl_world_size"] is None
+
+
+@pytest.mark.parametrize("dim,bits,metric,top_k,scale", [(128, 7, 0, 10, 1.0), (128, 7, 0, 100, 1.0), (960, 7, 0, 10, 1.0), (960, 3, 1, 10, 1.0),
+                                                         (256, 1, 0, 10, 1.0), (128, 7, 0, 10, 1e4), (64, 3, 0, 5, 1e-4), (768, 7, 0, 10, 1.0)])
+def test_select_time_bound_is_an_upper_bound_of_the_kth_distance(dim, bits, metric, top_k, scale):
+    """The claim behind the lazy selection, checked directly: whenever the selection ran lazily, the bound it classified lists
+    against (the Cauchy-Schwarz T_ub, or the exact head evaluation's T' — the tap in dead_skipped[2]) is >= the k-th distance the
+    search finally returns (= the reference's: results are compared with the oracle first).  A bound below the final k-th distance
+    would be a violated claim even where, by luck, no list was dropped wrongly."""
+    import torch
+    n, nlist, nq, nprobe = 30000, 150, 128, 64
+    rng = np.random.default_rng(5000 + dim + top_k)
+    data = (make_dataset(n, dim, 40, 5000 + dim, normalize=(metric == 1)) * np.float32(scale)).astype(np.float32)
+    q = (data[rng.choice(n, nq, replace=False)] + np.float32(0.05 * scale) * rng.standard_normal((nq, dim)).astype(np.float32)).astype(np.float32)
+    _, built = build_index(nlist=nlist, total_bits=bits, metric=metric, seed=50, data=data, dim=dim)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    ids, sc, cnt = _compare(built, idx, q, top_k, nprobe)
+    dev = torch.device("cuda", 0)
+    for hx in (1, 0):
+        idx.set_option("head_exact", hx)
+        qd = torch.from_numpy(q).to(dev)
+        d_i = torch.zeros(nq, top_k, dtype=torch.int64, device=dev)
+        d_s = torch.zeros(nq, top_k, dtype=torch.float32, device=dev)
+        d_c = torch.zeros(nq, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        idx.search_batch_device(qd.data_ptr(), nq, dim, top_k, nprobe, d_i.data_ptr(), d_s.data_ptr(), d_c.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        taps = idx.debug_copy_workspace(st.cuda_stream, "dead_skipped", np.empty((4, nq), np.uint32))
+        idx.release_stream(st.cuda_stream)
+        assert np.array_equal(d_i.cpu().numpy().view(np.uint64), ids)
+        bound = taps[2].view(np.float32)
+        full = cnt == top_k
+        kth = np.where(metric == 0, sc[:, top_k - 1], -sc[:, top_k - 1])
+        entered = np.isfinite(bound) | np.isinf(bound)  # NaN = the lazy path was not entered for that query
+        ok = ~full | ~entered | (bound >= kth)
+        assert ok.all(), (hx, np.nonzero(~ok)[0][:8], bound[~ok][:4], kth[~ok][:4])
+        assert (entered & full).mean() > 0.5
+        if hx == 1:
+            ran, trips = idx.head_exact_stats()
+            assert trips == 0                      # the geometry guard never trips
+            assert ran > 0 or dim != 128           # (d = 128: the Cauchy-Schwarz bound leaves many lists alive, the exact evaluation must run)
+    idx.close()
