@@ -387,3 +387,33 @@ def test_select_time_bound_is_an_upper_bound_of_the_kth_distance(dim, bits, metr
             assert trips == 0                      # the geometry guard never trips
             assert ran > 0 or dim != 128           # (d = 128: the Cauchy-Schwarz bound leaves many lists alive, the exact evaluation must run)
     idx.close()
+
+
+def test_bench_under_torchrun_with_one_rank_is_the_plain_protocol():
+    """The driver's scaling run starts N = 1 like the other points — `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1` — while its headline run starts `python bench.py --gpus 1` directly.  Both must follow ONE protocol (no process group,
+    the same legs, the same `value`): SCALE's N = 1 point then agrees with BENCH."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from test_gpu_round3 import _run_bench
+    args = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-extras", "--no-cpu", "--nbatches", "4", "--min-seconds", "0", "--no-latency",
+            "--n", "200000", "--nlist", "1024", "--nprobe", "32"]
+    plain = _run_bench(args, {})
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RBQ_BENCH_FORCE_DIST", "RBQ_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    tr = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "higher_is_better", "timed_regions", "rccl_world_size"):
+        assert tr[k] == plain[k], (k, tr[k], plain[k])
+    assert tr["config"] == plain["config"] and tr["rccl_world_size"] is None and len(tr["per_rank_queries_per_s"]) == 1
+    assert tr["pruned"]["launches"] == plain["pruned"]["launches"] == 6
+    assert abs(tr["recall_at_10"] - plain["recall_at_10"]) < 1e-9          # the same index, the same queries, the same results
+    assert 0.5 < tr["value"] / plain["value"] < 2.0                          # (two short runs: the rate itself is noisy)
