@@ -140,7 +140,10 @@ hipError_t launch_select_mfma(const SelectParams& p, int device, hipStream_t s) 
     g.hx_nv = 0;
     size_t regionN = g.stage_rows ? rowsN : 0;
     if (p.lazy && p.head_exact && p.lut && p.top_k <= kHxMaxVec && p.D % 16 == 0) {
-        uint32_t nv = (uint32_t)((16384u * 8u / p.Dc) / 32u * 32u);
+#ifndef RBQ_HX_BUDGET
+#define RBQ_HX_BUDGET (16384u * 8u)
+#endif
+        uint32_t nv = (uint32_t)(((uint32_t)RBQ_HX_BUDGET / p.Dc) / 32u * 32u); // vectors evaluated: ~128 K code dimensions per query
         nv = nv < 64u ? 64u : (nv > kHxMaxVec ? kHxMaxVec : nv);
         const size_t hxN = (hx_scratch_bytes(p.D, p.Dc, p.ex_bits, nv) + 15) & ~(size_t)15;
         if (lds + std::max(regionN, hxN) <= 64 * 1024) { g.hx_nv = nv; regionN = std::max(regionN, hxN); }

@@ -371,7 +371,13 @@ struct SelectGeom {
     uint32_t hx_nv;      // exact head evaluation: vectors of the nearest list whose 1-bit estimate is evaluated (0: off); its LDS
                          // scratch (u8 LUT | zero-padded query | three floats per vector) shares the region of the LDS scorer's rows
 };
-constexpr uint32_t kHxTrigger = 6;   // lists alive beyond the head under the Cauchy-Schwarz bound that make the exact evaluation worth its cost
+#ifndef RBQ_HX_TRIGGER
+#define RBQ_HX_TRIGGER 6
+#endif
+#ifndef RBQ_HX_REFINE_MULT
+#define RBQ_HX_REFINE_MULT 2
+#endif
+constexpr uint32_t kHxTrigger = RBQ_HX_TRIGGER; // lists alive beyond the head under the Cauchy-Schwarz bound that make the exact evaluation worth its cost
 constexpr uint32_t kHxMaxVec = 256;  // one thread per vector
 
 // ---- canonical scores of shortlist entries ----------------------------------------------------------------------------
@@ -721,7 +727,7 @@ __device__ __forceinline__ float head_exact_bound(const SelectParams& P, const S
         return r;
     }
     // phase 2: the R smallest estimates are refined (16 lanes per vector, the reference's FMA order: bit-identical to k_scan)
-    const uint32_t R0 = 2u * top_k > 16u ? 2u * top_k : 16u;
+    const uint32_t R0 = (uint32_t)RBQ_HX_REFINE_MULT * top_k > 16u ? (uint32_t)RBQ_HX_REFINE_MULT * top_k : 16u;
     const uint32_t R = R0 < nv ? R0 : nv;
     if (tid < nv) {
         const float my = vEst[tid];

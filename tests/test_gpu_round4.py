@@ -420,3 +420,45 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_protocol():
     assert tr["pruned"]["launches"] == plain["pruned"]["launches"] == 6
     assert abs(tr["recall_at_10"] - plain["recall_at_10"]) < 1e-3          # (the harness k-means sums with atomics: two builds differ in a few list assignments)
     assert 0.5 < tr["value"] / plain["value"] < 2.0                          # (two short runs: the rate itself is noisy)
+
+
+def test_staging_helpers_under_concurrent_callers_and_replicas():
+    """Pageable 1024 x 960 f32 query batches (3.9 MB: the staging helper threads engage) from four caller threads at once on a
+    handle with two replicas (each shard has its own lanes and its own helper pool): every call returns the device entry's bits."""
+    import threading
+    import torch
+    n, dim, nlist, top_k, nprobe = 20000, 960, 64, 10, 16
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=7, seed=4951)
+    idx = rq.IvfRabitqIndex.from_built(built, devices=[0, 0])
+    one = rq.IvfRabitqIndex.from_built(built)
+    dev = torch.device("cuda", 0)
+    sets = []
+    for j in range(4):
+        q = make_dataset(1024, dim, 16, 4960 + j)
+        qd = torch.from_numpy(q).to(dev)
+        d_i = torch.empty(1024, top_k, dtype=torch.int64, device=dev)
+        d_s = torch.empty(1024, top_k, dtype=torch.float32, device=dev)
+        d_c = torch.empty(1024, dtype=torch.int32, device=dev)
+        one.search_batch_device(qd.data_ptr(), 1024, dim, top_k, nprobe, d_i.data_ptr(), d_s.data_ptr(), d_c.data_ptr(), stream=None)
+        torch.cuda.synchronize(dev)
+        sets.append((q, d_i.cpu().numpy().view(np.uint64), d_s.cpu().numpy().view(np.uint32), d_c.cpu().numpy().view(np.uint32)))
+    errors = []
+
+    def worker(t):
+        try:
+            for r in range(6):
+                q, wi, ws, wc = sets[(t + r) % 4]
+                ids, sc, cnt, _ = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe))
+                if not (np.array_equal(ids, wi) and np.array_equal(sc.view(np.uint32), ws) and np.array_equal(cnt, wc)):
+                    errors.append((t, r))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[:4]
+    idx.set_option("host_stage_helpers", 0)
+    ids, sc, cnt, _ = idx.batch_search_raw(sets[0][0], rq.SearchParams(top_k, nprobe))
+    assert np.array_equal(ids, sets[0][1]) and np.array_equal(cnt, sets[0][3])
+    idx.close(); one.close()
