@@ -474,8 +474,9 @@ def test_random_configurations_match_oracle(seed):
 
 
 def test_gpu_matches_committed_vectors():
-    """The committed golden vectors (tests/golden/oracle_vectors.npz: ids, scores, counts, diagnostics of seeded
-    cases) through the GPU path — independent of whatever oracle library is on the box."""
+    """REGRESSION guard, not parity evidence: tests/golden/oracle_vectors.npz holds outputs of THIS repository's oracle for seeded
+    cases (the reference's tests hold no end-to-end search outputs).  The GPU path must keep reproducing them whatever oracle
+    library is on the box."""
     import importlib.util
     import os
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
