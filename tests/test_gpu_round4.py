@@ -419,7 +419,7 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_protocol():
     assert tr["config"] == plain["config"] and tr["rccl_world_size"] is None and len(tr["per_rank_queries_per_s"]) == 1
     assert tr["pruned"]["launches"] == plain["pruned"]["launches"] == 6
     assert abs(tr["recall_at_10"] - plain["recall_at_10"]) < 1e-3          # (the harness k-means sums with atomics: two builds differ in a few list assignments)
-    assert 0.5 < tr["value"] / plain["value"] < 2.0                          # (two short runs: the rate itself is noisy)
+    assert 0.2 < tr["value"] / plain["value"] < 5.0                          # (two six-step runs: the rate itself is noisy)
 
 
 def test_staging_helpers_under_concurrent_callers_and_replicas():
