@@ -99,6 +99,9 @@ struct SelectParams {
     const float *f_add_ex, *f_rescale_ex;
     uint32_t Dc;
     uint32_t n_blocks;            // blocks of the index (the exact head evaluation checks its geometry against it)
+    const uint32_t* filter;       // dense id filter of search_filtered (or null) and the ids it tests: under a filter only the exact
+    uint64_t filter_nbits;        // head evaluation — which counts filter-passing vectors only — can bound the k-th distance
+    const uint64_t* ids;
     int head_exact;               // 0: Cauchy-Schwarz bound only (round 3)
     int fault_dead_all;           // TEST ONLY (debug option lazy_fault_inject, default 0): T_ub := -inf — every list behind the head is
                                   // declared dead whatever its bounds say: a deliberately WRONG selection, so that the

@@ -703,8 +703,12 @@ __device__ __forceinline__ float head_exact_bound(const SelectParams& P, const S
         est = est + rs;
         const float er = fminf(f_error * ge_lo, f_error * ge_hi);
         const float lb = est - er;
-        const bool ok = hx_tame(f_add) && hx_tame(f_rescale) && hx_tame(f_error) && hx_tame(ip) && hx_tame(rs) && hx_tame(e0) && hx_tame(est) &&
-                        hx_tame(f_error * ge_lo) && hx_tame(f_error * ge_hi) && hx_tame(lb) && qc.amax <= 65535.0f;
+        bool ok = hx_tame(f_add) && hx_tame(f_rescale) && hx_tame(f_error) && hx_tame(ip) && hx_tame(rs) && hx_tame(e0) && hx_tame(est) &&
+                  hx_tame(f_error * ge_lo) && hx_tame(f_error * ge_hi) && hx_tame(lb) && qc.amax <= 65535.0f;
+        if (P.filter) { // search_filtered: only vectors the filter lets through are ever pushed (the scan's own test, src/ivf.rs:2018-2022)
+            const uint32_t id32 = (uint32_t)P.ids[(size_t)(gb + b) * 32u + l32];
+            ok = ok && ((uint64_t)id32 < P.filter_nbits) && ((P.filter[id32 >> 5] >> (id32 & 31u)) & 1u);
+        }
         vEst[tid] = ok ? est : INFINITY;
         vLb[tid] = lb;
         vIp[tid] = ip;
@@ -1217,8 +1221,15 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 if (cum >= P.top_k) atomicMin(reinterpret_cast<int*>(&s_tub), total_key(myU));
             }
             __syncthreads();
-            const float T_ub = P.fault_dead_all ? -INFINITY : key_to_float((int32_t)s_tub); // (fault_dead_all: test-only fault injection)
+            // Under a filter the Cauchy-Schwarz bound proves nothing (it counts vectors that may never be pushed): the bound comes from
+            // the exact head evaluation alone, which tests every vector's filter bit (round 4); +inf = this query stays eager.
+            float T_ub = P.fault_dead_all ? -INFINITY : key_to_float((int32_t)s_tub); // (fault_dead_all: test-only fault injection)
             const float cost_maxh = key_to_float((int32_t)s_maxh);
+            bool hx_done = false;
+            if (P.filter) { // (uniform)
+                T_ub = (G.hx_nv && P.head_exact) ? head_exact_bound(P, G, qc, keys, s_head, s_hgb, s_hn, s_hcn, h, eps, reinterpret_cast<unsigned char*>(rows), qrot, part, hist, q, tid, cost_of) : INFINITY;
+                hx_done = true;
+            }
             lazy = T_ub < INFINITY;
             dbg_tub = __float_as_uint(T_ub);
             if (tid < h) s_todo[tid] = s_head[tid];
@@ -1265,7 +1276,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 // That race was a rare "memory access fault" in the first builds of this step.)
                 const uint32_t need1 = s_need;
                 __syncthreads();
-                if (G.hx_nv && P.head_exact && need1 - h > kHxTrigger) { // (uniform)
+                if (G.hx_nv && P.head_exact && !hx_done && need1 - h > kHxTrigger) { // (uniform)
                     const float T2 = head_exact_bound(P, G, qc, keys, s_head, s_hgb, s_hn, s_hcn, h, eps, reinterpret_cast<unsigned char*>(rows), qrot, part, hist, q, tid, cost_of);
                     if (T2 < T_ub) {
                         m_dead = 0ull;

@@ -221,6 +221,7 @@ struct Replica {
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     bool head_exact = true;  // lazy selection: a bound of the k-th distance from real estimates of the nearest list's first vectors
+    bool lazy_filter = true; // search_filtered: lazy selection on the exact head evaluation's bound (filter-passing vectors only)
     bool lazy_fault_inject = false; // TEST ONLY: makes the lazy selection wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     bool profile_counters = true; // an open profile keeps the traffic counters (option profile_counters = 0: stage timings only —
@@ -483,7 +484,7 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
     ix->dim = src->dim; ix->D = src->D; ix->Dc = src->Dc; ix->metric = src->metric; ix->rotator = src->rotator; ix->ex_bits = src->ex_bits;
     ix->n_vectors = src->n_vectors; ix->n_lists = src->n_lists; ix->n_blocks = src->n_blocks; ix->trunc = src->trunc; ix->fac = src->fac;
     ix->cnorm2_max = src->cnorm2_max; ix->h_list_n = src->h_list_n; ix->nblk_desc_prefix = src->nblk_desc_prefix;
-    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select; ix->profile_counters = src->profile_counters; ix->head_exact = src->head_exact;
+    ix->exact_rank = src->exact_rank; ix->force_rank_fallback = src->force_rank_fallback; ix->lazy_select = src->lazy_select; ix->profile_counters = src->profile_counters; ix->head_exact = src->head_exact; ix->lazy_filter = src->lazy_filter;
     for (size_t i = 0; i < sizeof(ix->arrays) / sizeof(ix->arrays[0]); ++i) {
         const Arr* s = src->arrays[i];
         Arr* d = ix->arrays[i];
@@ -1122,7 +1123,11 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     sp.dead_skipped = (uint32_t*)w->dead_skipped.p; sp.top_k = top_k; sp.ex_bits = ix->ex_bits;
     // lazy selection: not with a filter (filtered vectors are never pushed, so no select-time bound of the k-th distance
     // exists) and not when every probed block is to be streamed
-    sp.lazy = (ix->lazy_select && !d_filter && !ix->no_block_bound) ? 1 : 0;
+    // (round 4: under a filter the exact head evaluation can still bound the k-th distance — it looks at real vectors and counts
+    // the ones that pass; with diagnostics the skip counter of a dropped list would need every id's filter bit: eager then)
+    const bool lazy_with_filter = ix->lazy_filter && ix->head_exact && !d_diag;
+    sp.lazy = (ix->lazy_select && (!d_filter || lazy_with_filter) && !ix->no_block_bound) ? 1 : 0;
+    sp.filter = d_filter; sp.filter_nbits = filter_nbits; sp.ids = (const uint64_t*)ix->ids.p;
     sp.exact_members = d_diag ? 1 : 0;
     sp.fault_dead_all = ix->lazy_fault_inject ? 1 : 0;
     sp.lut = (const uint8_t*)w->lut.p; sp.blocks = (const uint8_t*)ix->blocks.p; sp.ex_codes = (const uint8_t*)ix->ex.p;
@@ -1848,6 +1853,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
         else if (!std::strcmp(name, "lazy_fault_inject")) ix->lazy_fault_inject = value != 0;
         else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
+        else if (!std::strcmp(name, "lazy_filter")) ix->lazy_filter = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
         else if (!std::strcmp(name, "host_stage_helpers")) ix->host_stage_helpers = value != 0;
         else if (!std::strcmp(name, "rerank")) {

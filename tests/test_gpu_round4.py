@@ -462,3 +462,48 @@ def test_staging_helpers_under_concurrent_callers_and_replicas():
     ids, sc, cnt, _ = idx.batch_search_raw(sets[0][0], rq.SearchParams(top_k, nprobe))
     assert np.array_equal(ids, sets[0][1]) and np.array_equal(cnt, sets[0][3])
     idx.close(); one.close()
+
+
+@pytest.mark.parametrize("dim,bits,metric,top_k", [(128, 7, 0, 10), (960, 7, 0, 10), (256, 3, 1, 10), (128, 1, 0, 5), (128, 7, 0, 100)])
+def test_filtered_search_with_lazy_selection(dim, bits, metric, top_k):
+    """search_filtered (src/ivf.rs:1723-1730, :2018-2022) with the lazy selection ON: under a filter the bound of the k-th distance
+    comes from the exact head evaluation alone (it tests every evaluated vector's filter bit; the Cauchy-Schwarz bound counts vectors
+    that may never be pushed and is not used).  Filters passing 90 / 50 / 10 / 1 % of the ids, ragged filter lengths: the oracle's ids,
+    counts, scores and (eager, with diagnostics) counters; the same bits with `lazy_filter` off; and lists really are dropped."""
+    import torch
+    n, nlist, nq, nprobe = 30000, 150, 64, 64
+    rng = np.random.default_rng(5200 + dim + bits)
+    data = make_dataset(n, dim, 40, 5200 + dim, normalize=(metric == 1))
+    q = (data[rng.choice(n, nq, replace=False)] + 0.05 * rng.standard_normal((nq, dim)).astype(np.float32)).astype(np.float32)
+    _, built = build_index(nlist=nlist, total_bits=bits, metric=metric, seed=52, data=data, dim=dim)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    dev = torch.device("cuda", 0)
+    dropped_any = False
+    for frac, nbits in ((0.9, n), (0.5, n), (0.1, n - 777), (0.01, n)):
+        allowed = np.nonzero(rng.random(nbits) < frac)[0]
+        words = np.zeros((nbits + 31) // 32, np.uint32)
+        np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+        idx.set_option("lazy_filter", 1)
+        ids1, sc1, cnt1 = _compare(built, idx, q, top_k, nprobe, words, nbits)   # diagnostics run = eager; the run without = lazy
+        idx.set_option("lazy_filter", 0)
+        ids0, sc0, cnt0 = _compare(built, idx, q, top_k, nprobe, words, nbits)
+        idx.set_option("lazy_filter", 1)
+        assert np.array_equal(ids0, ids1) and np.array_equal(cnt0, cnt1) and np.array_equal(sc0.view(np.uint32), sc1.view(np.uint32))
+        # how many lists reach the scan under this filter (device entry, no diagnostics)
+        qd = torch.from_numpy(q).to(dev)
+        fd = torch.from_numpy(words.view(np.int32)).to(dev)
+        d_i = torch.zeros(nq, top_k, dtype=torch.int64, device=dev)
+        d_s = torch.zeros(nq, top_k, dtype=torch.float32, device=dev)
+        d_c = torch.zeros(nq, dtype=torch.int32, device=dev)
+        st = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        idx.search_batch_device(qd.data_ptr(), nq, dim, top_k, nprobe, d_i.data_ptr(), d_s.data_ptr(), d_c.data_ptr(), stream=st.cuda_stream,
+                                d_filter=fd.data_ptr(), filter_nbits=nbits)
+        torch.cuda.synchronize(dev)
+        taps = idx.debug_copy_workspace(st.cuda_stream, "dead_skipped", np.empty((2, nq), np.uint32))
+        idx.release_stream(st.cuda_stream)
+        assert np.array_equal(d_i.cpu().numpy().view(np.uint64), ids1)
+        if frac >= 0.5:
+            dropped_any |= bool((taps[1] < nprobe).mean() > 0.3)
+    assert dropped_any or bits == 1 and dim == 128, "the lazy selection never dropped a list under a filter"
+    idx.close()
