@@ -34,6 +34,12 @@ using rbq_host::ListSrc;
 using rbq_host::OutPack;
 using rbq_host::align_up;
 
+// The HIP runtime multiplexes a process's streams over FOUR hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and two of this
+// library's lanes (or two caller streams) on one queue serialise their kernels: 16 queues are worth 5-15 % of the pipelined rate
+// (DESIGN 5).  The variable is read when the runtime initialises, so the library asks for 16 when it is LOADED — before the host's first
+// HIP call in the usual case of a program linked against it — and only if the host has not chosen a value itself.
+__attribute__((constructor)) static void rbq_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+
 namespace {
 
 thread_local std::string g_err;

@@ -100,3 +100,21 @@ def test_missing_hip_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(ix, "LIB_PATH", "/nonexistent/librbq.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ix.lib()
+
+
+def test_library_asks_for_16_hardware_queues_unless_the_host_chose():
+    """librbq.so's load-time constructor sets GPU_MAX_HW_QUEUES=16 (read by the HIP runtime when it initialises) only when the host
+    has not set the variable itself."""
+    import subprocess
+    import sys
+    code = ("import ctypes, os, sys\n"
+            "lib = ctypes.CDLL(%r)\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())\n") % ix.LIB_PATH
+    for preset, want in ((None, "16"), ("8", "8")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert out.stdout.strip().splitlines()[-1] == want, (preset, out.stdout)
