@@ -1,7 +1,7 @@
 """Per-call time of rbq_search_batch (host buffers in and out, ONE caller thread) against the host-path switches:
 zero-copy query reads, staging helper threads (pageable queries), sub-batch size x lanes.  Median / p10 of many calls (the box's host CPUs are shared:
 single regions scatter), ids checked against the device entry.
-python tools/host_call_probe.py [n] [nlist]        HOST_PROBE_SHAPES="256x4,512x2" HOST_PROBE_NQ="1024,4096"
+python tools/host_call_probe.py [n] [nlist]        HOST_PROBE_SHAPES="256x4,512x2" HOST_PROBE_NQ="1024,4096" HOST_PROBE_TOPK=100 HOST_PROBE_OPTIONS="exact_heap=1"
 """
 import ctypes as C
 import os
@@ -19,7 +19,7 @@ import rabitq_rs_amd as rq  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 nlist = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-dim, top_k, nprobe = 960, 10, 128
+dim, top_k, nprobe = 960, int(os.environ.get("HOST_PROBE_TOPK", "10")), 128
 dev = torch.device("cuda", 0)
 mix = bench.Mixture(torch, dev, dim, nlist, "mixture_id32", False)
 x = mix.draw(n, 20260105)
@@ -29,6 +29,9 @@ small = rq.builder.train_with_clusters(xs, cent.cpu().numpy(), (np.arange(8192) 
 idx = rq.IvfRabitqIndex.build_on_device(small.hdr_ptr, cent.cpu().numpy(), x.data_ptr(), assign.to(torch.int32).contiguous().data_ptr(), n,
                                         small.t_const)
 del x
+for kv in os.environ.get("HOST_PROBE_OPTIONS", "").split():
+    k_, v_ = kv.split("=")
+    idx.set_option(k_, int(v_))
 lib = rq.index.lib()
 NSETS = 8
 
