@@ -289,6 +289,12 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *   "debug_replica" r    which replica rbq_debug_copy_index / rbq_debug_copy_workspace read */
 int rbq_debug_set_option(rbq_index* idx, const char* name, int value);
 
+/* OPT-IN process-wide defaults, for a host that wants the library's recommendation applied: sets GPU_MAX_HW_QUEUES=16 in the process
+ * environment unless the variable is already set (the HIP runtime reads it when it initialises and multiplexes all streams of the
+ * process over 4 hardware queues otherwise; two batches on one queue serialise: 5-15 % of the pipelined rate).  Call it
+ * BEFORE the first HIP call of the process and before other threads exist (setenv is not thread-safe); it changes the queue
+ * configuration of every HIP user in the process, which is why the library never does it by itself.  Returns RBQ_OK or RBQ_IO. */
+int rbq_process_defaults(void);
 const char* rbq_strerror(int code);
 /* Copies the calling thread's last error detail (e.g. "checksum mismatch",
  * "expected 960, got 128") into buf; returns its full length. */

@@ -185,6 +185,9 @@ fn map_err(rc: c_int, expected: usize, got: usize) -> Result<(), RabitqError> {
 pub struct GpuIvf {
     h: *mut RbqIndex,
     dim: usize,
+    /// 1 + the largest id of the index when it is known (an index built by the crate stores ids 0..len, src/ivf.rs:1181,1192-1198):
+    /// filter bits at or beyond it can never match a vector, so the dense bitset of `search_filtered` stops there.
+    id_bound: Option<u64>,
 }
 
 // rbq_search_batch is re-entrant on one handle (include/rbq.h); the reference's search is `&self` and is called from
@@ -202,7 +205,9 @@ impl GpuIvf {
     pub fn from_index_on(index: &IvfRabitqIndex, devices: &[i32]) -> Result<Self, RabitqError> {
         let mut buf = Vec::new();
         index.save_to_writer(&mut buf)?;
-        Self::from_rbq1_bytes(&buf, devices)
+        let mut g = Self::from_rbq1_bytes(&buf, devices)?;
+        g.id_bound = Some(index.len() as u64); // ids of a crate-built index are the vector indexes 0..len
+        Ok(g)
     }
 
     /// An RBQ1-v3 byte stream as written by `save_to_writer` / `save_to_path`; validated like `load_from_reader`
@@ -214,7 +219,7 @@ impl GpuIvf {
         let rc = unsafe { rbq_index_load_rbq1(bytes.as_ptr() as *const c_void, bytes.len(), n, p, &mut h) };
         map_err(rc, 0, 0)?;
         let dim = unsafe { rbq_index_dim(h) } as usize;
-        Ok(Self { h, dim })
+        Ok(Self { h, dim, id_bound: None }) // (a stream of unknown origin may hold any u64 ids)
     }
 
     pub fn len(&self) -> usize {
@@ -243,7 +248,7 @@ impl GpuIvf {
         params: SearchParams,
         filter: &RoaringBitmap,
     ) -> Result<Vec<SearchResult>, RabitqError> {
-        let (words, nbits) = dense_words(filter);
+        let (words, nbits) = dense_words(filter, self.id_bound);
         self.search_one(query, params, Some((&words, nbits)), None)
     }
 
@@ -376,8 +381,12 @@ struct Scratch {
     cnt: Option<PinnedBuf<u32>>,
 }
 impl Scratch {
+    /// Page-locked memory is a scarce, per-thread resource here (one scratch per Rayon worker): a buffer that a single large batch
+    /// once blew up is given back when a call needs less than a quarter of it (and it holds more than 16 MB).
     fn grow<T: Copy>(slot: &mut Option<PinnedBuf<T>>, len: usize) -> bool {
-        if slot.as_ref().map_or(0, |b| b.as_slice().len()) >= len {
+        let have = slot.as_ref().map_or(0, |b| b.as_slice().len());
+        let oversized = have > 4 * len.max(1) && have * std::mem::size_of::<T>() > (16 << 20);
+        if have >= len && !oversized {
             return true;
         }
         *slot = PinnedBuf::new(len + len / 4);
@@ -392,13 +401,21 @@ thread_local! {
 }
 
 /// RoaringBitmap -> dense little-endian words: bit i of the bitset set <=> `filter.contains(i)`.
-fn dense_words(filter: &RoaringBitmap) -> (Vec<u32>, u64) {
-    let nbits = match filter.max() {
+/// `id_bound`: bits at or beyond it are dropped (they cannot match an indexed vector) — a filter that happens to contain one
+/// high u32 id would otherwise cost 512 MB of zeros per call.
+fn dense_words(filter: &RoaringBitmap, id_bound: Option<u64>) -> (Vec<u32>, u64) {
+    let mut nbits = match filter.max() {
         Some(m) => m as u64 + 1,
         None => 0,
     };
+    if let Some(b) = id_bound {
+        nbits = nbits.min(b);
+    }
     let mut words = vec![0u32; ((nbits + 31) / 32) as usize];
     for id in filter.iter() {
+        if (id as u64) >= nbits {
+            break; // (ascending iteration)
+        }
         words[(id >> 5) as usize] |= 1u32 << (id & 31);
     }
     (words, nbits)

@@ -56,6 +56,11 @@ def lib():
             getattr(L, n).argtypes = [f32p]
         L.ref_ip_packed_ex_avx512.restype = C.c_float
         L.ref_ip_packed_ex_avx512.argtypes = [f32p, u8p, C.c_size_t, C.c_uint32]
+        for n in ("ref_ip_packed_ex_avx2_order", "ref_ip_packed_ex_avx2_real", "ref_ip_packed_ex_scalar_order"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [f32p, u8p, C.c_size_t, C.c_uint32]
+        L.ref_set_variant.argtypes = [C.c_int]
+        L.ref_get_variant.restype = C.c_int
         L.ref_ex_dot.restype = C.c_float
         L.ref_ex_dot.argtypes = [f32p, u8p, C.c_size_t, C.c_uint32]
         L.ref_select_probes.restype = C.c_size_t
@@ -159,3 +164,50 @@ def posting_scan_batch(built, queries, top_k, list_ids, list_counts, nthreads=0)
     rc = lib().ref_posting_scan_batch(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(q), nq, qd, top_k, _p(li), _p(lc),
                                       li.shape[1], _p(ids), _p(scores), _p(counts), nthreads)
     return rc, ids, scores, counts
+
+
+VARIANTS = {"default": 0, "ex_avx2": 1, "ex_scalar": 2, "epilogue_scalar": 4, "ex_scalar+epilogue_scalar": 6, "contract": 8,
+            "ex_avx2+contract": 9}
+
+
+class variant:
+    """with oracle.variant("ex_avx2"): ...   — one of the reference's other compile-time numeric variants (rbq_ref.c)"""
+
+    def __init__(self, name_or_mask):
+        self.mask = VARIANTS[name_or_mask] if isinstance(name_or_mask, str) else int(name_or_mask)
+
+    def __enter__(self):
+        self.old = lib().ref_get_variant()
+        lib().ref_set_variant(self.mask)
+        return self
+
+    def __exit__(self, *a):
+        lib().ref_set_variant(self.old)
+
+
+def variant_diff_table(built, queries, top_k, nprobe, names=None):
+    """For every numeric variant: fraction of queries whose returned ids differ from the default variant's, fraction whose score
+    bits differ, and the largest relative score difference among queries with the same ids."""
+    rc, ids0, sc0, cnt0, _ = search_batch(built, queries, top_k, nprobe)
+    assert rc == 0
+    out = {}
+    for name in (names or [n for n in VARIANTS if n != "default"]):
+        with variant(name):
+            rc, ids, sc, cnt, _ = search_batch(built, queries, top_k, nprobe)
+        assert rc == 0
+        same_ids = (ids == ids0).all(axis=1) & (cnt == cnt0)
+        bits_same = np.array([np.array_equal(sc[q, :cnt0[q]].view(np.uint32), sc0[q, :cnt0[q]].view(np.uint32)) for q in range(len(ids))])
+        rel = 0.0
+        rel_scale = 0.0  # against max(|score|, the batch's median |score|): near-exact hits have scores near 0, where a relative
+        valid = np.arange(sc0.shape[1])[None, :] < cnt0[:, None]  # difference measures cancellation, not the variant
+        med = float(np.median(np.abs(sc0[valid]))) if valid.any() else 1.0
+        for q in np.nonzero(same_ids)[0]:
+            c = int(cnt0[q])
+            if c:
+                d = np.abs(sc[q, :c] - sc0[q, :c])
+                rel = max(rel, float(np.max(d / np.maximum(np.abs(sc0[q, :c]), 1e-30))))
+                rel_scale = max(rel_scale, float(np.max(d / np.maximum(np.abs(sc0[q, :c]), med))))
+        out[name] = {"queries": int(len(ids)), "ids_differ_frac": float(1.0 - same_ids.mean()),
+                     "score_bits_differ_frac": float(1.0 - (bits_same & same_ids).mean()), "max_rel_score_diff_same_ids": rel,
+                     "max_score_diff_over_scale_same_ids": rel_scale}
+    return out

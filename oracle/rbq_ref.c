@@ -48,6 +48,22 @@
 /* helpers                                                                   */
 /* ------------------------------------------------------------------------- */
 
+/* Numeric variants of the reference (ref_set_variant; 0 = the default restated above).  The crate picks its arithmetic at    */
+/* COMPILE time (cfg(target_feature), .cargo/config.toml:11-14), so a build for another host returns other last bits; these   */
+/* switches restate the other bodies so that tests/test_oracle_variants.py can measure what each is worth.  Bits:             */
+/*   REF_VAR_EX_AVX2     ip_packed_ex{2,6}_f32_avx2 (src/simd.rs:1722-1825): ONE 8-lane accumulator, two FMAs per 16 dims      */
+/*                       (dims 16t+l, then 16t+8+l), hsum lo128+hi128 / movehl / shuffle 0x55 — an AVX2-only host             */
+/*   REF_VAR_EX_SCALAR   ip_packed_ex{2,6}_f32_scalar (:1615-1713): one running sum, unfused `sum += c * q` in the scalar      */
+/*                       bodies' own order — a host without AVX2 (what CI's RUSTFLAGS="" builds, .github/workflows/ci.yml)     */
+/*   REF_VAR_EPI_SCALAR  compute_batch_distances_u16_scalar (:2039-2061): `delta * accu + sum_vl` NOT fused                   */
+/*   REF_VAR_CONTRACT    what `-C llvm-args=--ffast-math` may do IF the pinned LLVM honours it: every `a * b + c` of the path  */
+/*                       that the source leaves unfused becomes one fused multiply-add (math::dot / l2_distance_sqr AVX2       */
+/*                       bodies, the rest of the epilogue, the refine formula).  Reassociation and reciprocal division, which  */
+/*                       the same flag also permits, are compiler-version specific and are NOT restated.                       */
+static int g_variant = 0;
+void ref_set_variant(int v) { g_variant = v; }
+int ref_get_variant(void) { return g_variant; }
+
 static inline int32_t f32_bits(float x) { int32_t i; memcpy(&i, &x, 4); return i; }
 
 /* f32::total_cmp key (core::f32::total_cmp): flip the magnitude bits of negatives. */
@@ -72,6 +88,7 @@ float ref_dot(const float* a, const float* b, size_t len) {
     size_t chunks = len / 8, i = 0;
     for (; i < chunks * 8; i += 8)
         for (int l = 0; l < 8; ++l) {
+            if (g_variant & REF_VAR_CONTRACT) { acc[l] = fmaf(a[i + l], b[i + l], acc[l]); continue; }
             float p = a[i + l] * b[i + l];
             acc[l] = acc[l] + p;
         }
@@ -93,6 +110,7 @@ float ref_l2_distance_sqr(const float* a, const float* b, size_t len) {
     for (; i < chunks * 8; i += 8)
         for (int l = 0; l < 8; ++l) {
             float d = a[i + l] - b[i + l];
+            if (g_variant & REF_VAR_CONTRACT) { acc[l] = fmaf(d, d, acc[l]); continue; }
             float p = d * d;
             acc[l] = acc[l] + p;
         }
@@ -448,8 +466,19 @@ void ref_compute_batch_distances(const uint16_t* accu, float delta, float sum_vl
     for (int i = 0; i < 32; ++i) {
         float a = (float)(int32_t)accu[i];
         float ipv = fmaf(delta, a, sum_vl);
+        if ((g_variant & REF_VAR_EPI_SCALAR) && !(g_variant & REF_VAR_CONTRACT)) { /* src/simd.rs:2056: `lut_delta * accu + lut_sum_vl` */
+            float pm = delta * a;
+            ipv = pm + sum_vl;
+        }
         ip[i] = ipv;
         float t = ipv + k1x;
+        if (g_variant & REF_VAR_CONTRACT) {
+            float e0 = f_add[i] + g_add;
+            float e1 = fmaf(f_rescale[i], t, e0);
+            est[i] = e1;
+            lb[i] = fmaf(-f_error[i], g_error, e1);
+            continue;
+        }
         float r = f_rescale[i] * t;
         float e = f_add[i] + g_add;
         e = e + r;
@@ -588,9 +617,94 @@ static float ip_packed_ex2_fast(const float* q, const uint8_t* code, size_t D) {
     return _mm_cvtss_f32(c) + _mm_cvtss_f32(_mm_shuffle_ps(c, c, 0x55));
 }
 
+/* ip_packed_ex{2,6}_f32_avx2, src/simd.rs:1722-1825, in scalar C: lane l of ONE 8-lane accumulator takes dims 16t+l and then   */
+/* 16t+8+l (two FMAs per step); hsum: lo128 + hi128, movehl, shuffle 0x55                                                     */
+static void ex_codes16(const uint8_t* code, size_t t, uint32_t ex_bits, float* cf) {
+    if (ex_bits == 2) {
+        uint32_t w;
+        memcpy(&w, code + t * 4, 4);
+        for (int i = 0; i < 4; ++i)
+            for (int g = 0; g < 4; ++g) cf[i + 4 * g] = (float)((w >> (8 * i + 2 * g)) & 3u);
+    } else {
+        uint64_t lo;
+        uint32_t hi;
+        memcpy(&lo, code + t * 12, 8);
+        memcpy(&hi, code + t * 12 + 8, 4);
+        for (int l = 0; l < 16; ++l) {
+            uint32_t low4 = l < 8 ? (uint32_t)((lo >> (8 * l)) & 15u) : (uint32_t)((lo >> (8 * (l - 8) + 4)) & 15u);
+            uint32_t top2 = (hi >> (8 * (l & 3) + 2 * (l >> 2))) & 3u;
+            cf[l] = (float)(low4 | (top2 << 4));
+        }
+    }
+}
+float ref_ip_packed_ex_avx2_order(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits) {
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cf[16];
+    for (size_t t = 0; t < D / 16; ++t) {
+        ex_codes16(code, t, ex_bits, cf);
+        for (int l = 0; l < 8; ++l) s[l] = fmaf(cf[l], q[t * 16 + l], s[l]);
+        for (int l = 0; l < 8; ++l) s[l] = fmaf(cf[8 + l], q[t * 16 + 8 + l], s[l]);
+    }
+    float b[4];
+    for (int i = 0; i < 4; ++i) b[i] = s[i] + s[i + 4]; /* sum_lo + sum_hi */
+    float c0 = b[0] + b[2], c1 = b[1] + b[3];           /* + movehl */
+    return c0 + c1;                                     /* + shuffle 0x55 */
+}
+/* the same on REAL AVX2 instructions, as src/simd.rs:1722-1825 issues them (pins the scalar restatement above) */
+__attribute__((target("avx2,fma")))
+float ref_ip_packed_ex_avx2_real(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits) {
+    __m256 sum = _mm256_setzero_ps();
+    const int64_t MASK4 = 0x0f0f0f0f0f0f0f0fLL;
+    for (size_t t = 0; t < D / 16; ++t) {
+        __m128i c;
+        if (ex_bits == 2) {
+            int32_t w;
+            memcpy(&w, code + t * 4, 4);
+            c = _mm_and_si128(_mm_set_epi32(w >> 6, w >> 4, w >> 2, w), _mm_set1_epi8(3));
+        } else {
+            int64_t c4;
+            int32_t c2v;
+            memcpy(&c4, code + t * 12, 8);
+            memcpy(&c2v, code + t * 12 + 8, 4);
+            __m128i v4 = _mm_set_epi64x((c4 >> 4) & MASK4, c4 & MASK4);
+            __m128i v2 = _mm_and_si128(_mm_set_epi32(c2v >> 2, c2v, (int32_t)((uint32_t)c2v << 2), (int32_t)((uint32_t)c2v << 4)), _mm_set1_epi8(0x30));
+            c = _mm_or_si128(v2, v4);
+        }
+        __m256 f0 = _mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(c));
+        sum = _mm256_fmadd_ps(f0, _mm256_loadu_ps(q + t * 16), sum);
+        __m256 f1 = _mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_unpackhi_epi64(c, c)));
+        sum = _mm256_fmadd_ps(f1, _mm256_loadu_ps(q + t * 16 + 8), sum);
+    }
+    __m128 s128 = _mm_add_ps(_mm256_castps256_ps128(sum), _mm256_extractf128_ps(sum, 1));
+    __m128 s64 = _mm_add_ps(s128, _mm_movehl_ps(s128, s128));
+    __m128 s32 = _mm_add_ss(s64, _mm_shuffle_ps(s64, s64, 0x55));
+    return _mm_cvtss_f32(s32);
+}
+/* ip_packed_ex{2,6}_f32_scalar, src/simd.rs:1615-1713: one running sum, `sum += c * q` (mul, then add) */
+float ref_ip_packed_ex_scalar_order(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits) {
+    float sum = 0.0f, cf[16];
+    for (size_t t = 0; t < D / 16; ++t) {
+        ex_codes16(code, t, ex_bits, cf);
+        if (ex_bits == 2) { /* i = 0..3: codes i, i+4, i+8, i+12 (:1636-1647) */
+            for (int i = 0; i < 4; ++i)
+                for (int g = 0; g < 4; ++g) {
+                    float p = cf[i + 4 * g] * q[t * 16 + i + 4 * g];
+                    sum = sum + p;
+                }
+        } else { /* i = 0..15 (:1703-1706) */
+            for (int i = 0; i < 16; ++i) {
+                float p = cf[i] * q[t * 16 + i];
+                sum = sum + p;
+            }
+        }
+    }
+    return sum;
+}
+
 /* select_excode_ipfunc, src/simd.rs:3205-3215 */
 float ref_ex_dot(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits) {
     if (ex_bits == 0) return 0.0f;
+    if (g_variant & REF_VAR_EX_SCALAR) return ref_ip_packed_ex_scalar_order(q, code, D, ex_bits);
+    if (g_variant & REF_VAR_EX_AVX2) return ref_ip_packed_ex_avx2_order(q, code, D, ex_bits);
     if (ref_simd_level() >= 1) return ex_bits == 2 ? ip_packed_ex2_fast(q, code, D) : ip_packed_ex6_fast(q, code, D);
     return ex_bits == 2 ? ref_ip_packed_ex2(q, code, D) : ref_ip_packed_ex6(q, code, D);
 }
@@ -832,6 +946,11 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
                     float a = cl->f_add_ex[gi] + g_add;
                     float m = cl->f_rescale_ex[gi] * t;
                     distance = a + m;
+                    if (g_variant & REF_VAR_CONTRACT) { /* `binary_scale * ip + ex_dot` and `f_rescale_ex * t + a` fused */
+                        float t2 = fmaf(qc.binary_scale, ip[i], ex_dot);
+                        t2 = t2 + qc.kbx_sum_q;
+                        distance = fmaf(cl->f_rescale_ex[gi], t2, a);
+                    }
                 }
                 if (!isfinite(distance)) continue;
                 if (diag) diag->estimated++;

@@ -42,6 +42,13 @@ float    ref_ip_packed_ex6(const float* q, const uint8_t* code, size_t D);
 float    ref_ex_dot(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits);
 int      ref_heap_trace(const float* dist, const uint64_t* ids, size_t n, uint32_t top_k, uint64_t* out_ids, float* out_dist,
                         uint32_t* out_len);
+/* numeric variants of the reference (rbq_ref.c, "Numeric variants"): a bit mask, 0 = the default (target-cpu=native on AVX-512) */
+enum { REF_VAR_EX_AVX2 = 1, REF_VAR_EX_SCALAR = 2, REF_VAR_EPI_SCALAR = 4, REF_VAR_CONTRACT = 8 };
+void     ref_set_variant(int mask);
+int      ref_get_variant(void);
+float    ref_ip_packed_ex_avx2_order(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits);
+float    ref_ip_packed_ex_avx2_real(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits); /* real AVX2 instructions */
+float    ref_ip_packed_ex_scalar_order(const float* q, const uint8_t* code, size_t D, uint32_t ex_bits);
 int      ref_have_avx512(void);
 float    ref_reduce_add_16(const float* s);                 /* the halving tree the oracle uses for _mm512_reduce_add_ps */
 float    ref_reduce_add_16_avx512(const float* s);          /* the compiler's own _mm512_reduce_add_ps (0 without AVX-512) */

@@ -65,6 +65,10 @@ hipError_t launch_scan_more_dims(const ScanParams& P, uint32_t nq, size_t lds, i
                                  bool* handled); // k_scan2.hip
 
 hipError_t launch_scan(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (P.wave_kernel && scanw_serves(P)) {
+        const hipError_t e = launch_scanw(P, nq, device, s, ev0, ev1);
+        if (e != hipErrorNotSupported) return e; // (not supported: that instantiation spills registers — k_scan serves the call)
+    }
     const uint32_t D = P.D, Dc = P.Dc;
     const int nb = D == Dc ? scan_nb(D == 128 || D == 256 || D == 384 || D == 512 || D == 768 || D == 960 || D == 1024 || D == 1536 ? D : 0u) : 1;
     // (RBQ_SCAN_LDS_PAD: diagnostic — extra dynamic LDS per workgroup, occupancy experiments)

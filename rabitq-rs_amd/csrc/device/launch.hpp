@@ -132,6 +132,10 @@ hipError_t launch_probes_given(const ProbesGivenParams& p, hipStream_t s);
 
 // ev0/ev1: null, or an event pair carried by the dispatch packet itself (hipExtLaunchKernelGGL)
 hipError_t launch_scan(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+// k_scanw (scanw.hpp): the same scan with one wave per query; scanw_serves(): the call shapes it takes (launch_scan routes
+// to it when ScanParams::wave_kernel is set and it serves the call)
+bool scanw_serves(const ScanParams& P);
+hipError_t launch_scanw(const ScanParams& P, uint32_t nq, int device, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 // ---- k_build.hip -------------------------------------------------------------------------------------------------
 hipError_t launch_rotate_rows(const float* src, const uint32_t* map, uint32_t nrows, uint32_t dim, uint32_t D, int rotator,

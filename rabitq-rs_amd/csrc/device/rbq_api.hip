@@ -36,9 +36,12 @@ using rbq_host::align_up;
 
 // The HIP runtime multiplexes a process's streams over FOUR hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and two of this
 // library's lanes (or two caller streams) on one queue serialise their kernels: 16 queues are worth 5-15 % of the pipelined rate
-// (DESIGN 5).  The variable is read when the runtime initialises, so the library asks for 16 when it is LOADED — before the host's first
-// HIP call in the usual case of a program linked against it — and only if the host has not chosen a value itself.
-__attribute__((constructor)) static void rbq_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+// (DESIGN 5).  The variable is read when the runtime initialises.  The library does NOT touch the environment on its own (round 4 did,
+// from a load-time constructor: a silent change for every other HIP user of the process, and setenv under dlopen races with getenv in
+// a threaded host); rbq_process_defaults() is the explicit opt-in, for a host that wants the library's recommendation applied.
+extern "C" int rbq_process_defaults(void) {
+    return setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0) == 0 ? RBQ_OK : RBQ_IO;
+}
 
 namespace {
 
@@ -191,7 +194,16 @@ struct StageHelpers {
             }
         }
     }
-    void start() { for (auto& t : th) t = std::thread([this] { run(); }); }
+    // false: a thread could not be created (the ones that did start are shut down again; the caller stages inline)
+    bool start() {
+        try {
+            for (auto& t : th) t = std::thread([this] { run(); });
+        } catch (...) {
+            shutdown();
+            return false;
+        }
+        return true;
+    }
     void post(const Job& j) {
         pending.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> lk(mu); jobs.push_back(j); }
@@ -203,6 +215,15 @@ struct StageHelpers {
         for (auto& t : th) if (t.joinable()) t.join();
     }
 };
+
+// Default of the `scan_wave` option; RBQ_SCAN_WAVE=0|1|2 in the environment overrides it (A/B runs of the whole test suite).
+inline int scan_wave_default() {
+    static const int v = [] { const char* e = std::getenv("RBQ_SCAN_WAVE"); return e && *e ? std::atoi(e) : 2; }();
+    return v;
+}
+// scan_wave = 2: batches of at least this many queries go to k_scanw (a query costs one resident wave instead of four: the
+// pipelined rate), smaller ones to k_scan (four waves shorten ONE query's chain: the latency of a small call)
+constexpr uint64_t kScanWaveMinQueries = 128;
 
 // One device-resident copy of the index.
 struct Replica {
@@ -223,13 +244,18 @@ struct Replica {
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
     bool host_stage_helpers = true; // rbq_search_batch: pageable queries of a call's later sub-batches are staged by helper threads
-    std::unique_ptr<StageHelpers> stagers; // (created on the first pageable call, under `mu`)
+    std::unique_ptr<StageHelpers> stagers; // (created on the first pageable call, under `mu`; published only when all its threads run)
+    bool stagers_failed = false;           // thread creation failed once: pageable calls stage inline from then on
     bool no_block_bound = false, f32_rank = false, small_rank_tiles = false, wg_prep = false, exact_heap = false,
          force_rank_fallback = false, exact_rank = false; // rbq_debug_set_option
     bool head_exact = true;  // lazy selection: a bound of the k-th distance from real estimates of the nearest list's first vectors
     bool lazy_filter = true; // search_filtered: lazy selection on the exact head evaluation's bound (filter-passing vectors only)
     bool lazy_fault_inject = false; // TEST ONLY: makes the lazy selection wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
+    uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
+                               // workspace of the stream as the last full call wrote it — results are then those of THAT batch (rate probes only)
+    int scan_wave = scan_wave_default(); // which scan kernel serves a call: 0 = k_scan (one workgroup per query), 1 = k_scanw (one wave per
+                                         // query) wherever it serves the call shape, 2 = by batch size (kScanWaveMinQueries)
     bool profile_counters = true; // an open profile keeps the traffic counters (option profile_counters = 0: stage timings only —
                                   // the counters cost the pipelined run 2-3 %, bench.py collects them in a pass of their own)
     // host
@@ -288,7 +314,16 @@ struct ReplicaWorker {
             }
         }
     }
-    void start() { for (auto& t : th) t = std::thread([this] { run(); }); }
+    // false: a thread could not be created (the ones that did start are shut down again; the caller stages inline)
+    bool start() {
+        try {
+            for (auto& t : th) t = std::thread([this] { run(); });
+        } catch (...) {
+            shutdown();
+            return false;
+        }
+        return true;
+    }
     void post(std::function<void()> job) {
         pending.fetch_add(1, std::memory_order_release);
         { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(job)); }
@@ -1019,7 +1054,7 @@ struct ProfScope {
     // ext: the launch itself carries the event pair (hipExtLaunchKernelGGL: start/stop come from the dispatch
     // packet, no separate marker packets in the queue); otherwise the pair is recorded around the scope
     ProfScope(Replica* ix_, int st, hipStream_t s_, bool ext_ = false) : ix(ix_), stage(st), s(s_), ext(ext_) {
-        if (ix->profiling && ((ix->prof_mask >> st) & 1u)) {
+        if (ix->profiling && !stage_probes() && ((ix->prof_mask >> st) & 1u)) { // (a probed call launches nothing: no event pair for it)
             {
                 std::lock_guard<std::mutex> g(ix->mu);
                 if (ix->prof_seq[st]++ % ix->prof_every == 0) on = ix->ev_pool.take(ev);
@@ -1058,6 +1093,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.mstg = mstg ? 1u : 0u;
     P.prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
+    P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries)) ? 1u : 0u;
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
         int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);
@@ -1102,7 +1138,8 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         if ((rc = w->rot_lo.ensure(nq * D * 2))) return rc;
     }
     unsigned long long* prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
-    {
+    const uint32_t smask = ix->stage_mask;
+    if (smask & 1u) {
         ProfScope ps(ix, 0, stream);
         PrepParams p;
         p.queries = d_queries; p.nq = (uint32_t)nq; p.dim = ix->dim; p.D = D; p.Dc = Dc; p.rotator = (int)ix->rotator;
@@ -1146,13 +1183,13 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
             if ((rc = w->key_window.ensure((size_t)nq * select_exact_np2(nprobe) * 8))) return rc;
             kw = (uint64_t*)w->key_window.p;
         }
-        { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_exact(rp, stream)); }
-        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, ix->device, stream, kw)); }
+        if (smask & 2u) { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_exact(rp, stream)); }
+        if (smask & 4u) { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, ix->device, stream, kw)); }
     } else {
-        { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); }           // approximate scores: one MFMA GEMM
-        { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
+        if (smask & 2u) { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); }           // approximate scores: one MFMA GEMM
+        if (smask & 4u) { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
-    if ((rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
+    if ((smask & 8u) && (rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
                          /*mstg=*/false, (ix->exact_rank || big_nprobe) ? nullptr : (const uint32_t*)w->dead_skipped.p, stream)))
         return rc;
     if (ix->rerank && !stage_probes()) // optional, default off: exact re-scoring of the returned ids against the attached raw vectors
@@ -1268,11 +1305,19 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             __builtin_ia32_pause();
 #endif
         } } } wait_helpers{staged, n_helped};
-    if (!in_pinned && ix->host_stage_helpers && nsub >= 2 && nsub <= nlanes && nsub <= kMaxHelped && nq * query_dim * 4 >= (512u << 10)) {
-        {
-            std::lock_guard<std::mutex> lk(ix->mu);
-            if (!ix->stagers) { ix->stagers.reset(new StageHelpers()); ix->stagers->start(); }
+    bool helpers = !in_pinned && ix->host_stage_helpers && nsub >= 2 && nsub <= nlanes && nsub <= kMaxHelped && nq * query_dim * 4 >= (512u << 10);
+    if (helpers) {
+        // the helpers are published only once every thread of theirs runs (a half-started set used to stay installed, and
+        // jobs posted to it could wait forever); if a thread cannot be created the call stages inline, like a small one does
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (!ix->stagers && !ix->stagers_failed) {
+            std::unique_ptr<StageHelpers> sh(new (std::nothrow) StageHelpers());
+            if (sh && sh->start()) ix->stagers = std::move(sh);
+            else ix->stagers_failed = true;
         }
+        helpers = ix->stagers != nullptr;
+    }
+    if (helpers) {
         for (uint64_t j = 1; j < nsub; ++j) {
             Workspace* wj = lanes[j];
             if ((rc = wj->h_in.ensure(plan[j].second * query_dim * 4))) return rc; // (jobs posted so far are awaited by wait_helpers)
@@ -1849,6 +1894,8 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "exact_rank")) ix->exact_rank = value != 0;
         else if (!std::strcmp(name, "exact_heap")) ix->exact_heap = value != 0;
         else if (!std::strcmp(name, "lazy_select")) ix->lazy_select = value != 0;
+        else if (!std::strcmp(name, "stage_mask")) ix->stage_mask = (uint32_t)value & 0xfu;
+        else if (!std::strcmp(name, "scan_wave")) ix->scan_wave = value < 0 ? scan_wave_default() : (value > 2 ? 2 : value);
         else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;
         else if (!std::strcmp(name, "f32_rank")) ix->f32_rank = value != 0;
         else if (!std::strcmp(name, "wg_prep")) ix->wg_prep = value != 0;
@@ -1896,10 +1943,14 @@ int rbq_debug_stage_resources(rbq_index* h, uint64_t nq, uint32_t top_k, uint32_
     if (!g.ok) return fail(RBQ_DEVICE, "hipSetDevice failed");
     Workspace w; // scratch buffers are sized like a real call's (and freed on return); no kernel runs
     StageProbes probes;
-    stage_probes() = &probes;
-    const int rc = search_device(ix, &w, nullptr, nq, top_k, nprobe, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
-    stage_probes() = nullptr;
-    w.release();
+    int rc;
+    {
+        // the probe comes off this thread on EVERY exit path (an exception out of search_device — bad_alloc from a
+        // workspace — used to leave it installed, and every later search of the thread then launched nothing and returned RBQ_OK)
+        struct ProbeGuard { ProbeGuard(StageProbes* p) { stage_probes() = p; } ~ProbeGuard() { stage_probes() = nullptr; } } guard(&probes);
+        struct WsGuard { Workspace& w; ~WsGuard() { w.release(); } } wguard{w};
+        rc = search_device(ix, &w, nullptr, nq, top_k, nprobe, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     if (rc) return rc;
     for (int st = 0; st < 4; ++st) {
         const KernelProbe& k = probes.k[st];

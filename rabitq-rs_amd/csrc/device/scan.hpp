@@ -300,6 +300,104 @@ __device__ __forceinline__ void ex_dot_pair_units(const uint4* __restrict__ p0, 
     s0 = acc.x; s1 = acc.y;
 }
 
+// The same pair refine with EVERY unit of both vectors requested before the first one is decoded: one memory round trip per
+// refine round.  (ex_dot_pair_units above keeps one unit in flight, but hipcc rotates its loop so that each iteration waits
+// for its own loads — NU dependent round trips per round, 3 at D = 960: the ISA showed `global_load_dwordx4` at the loop top
+// followed by `s_waitcnt vmcnt(0)`.)  The units are decoded one after the other; the empty asm between them keeps the LDS
+// reads of unit j + 1 from being hoisted above unit j (all 3 x 21 query values alive: spills).
+#ifndef RBQ_PAIR_PIN
+#define RBQ_PAIR_PIN 4 // query values (LDS reads) in flight per decode stretch
+#endif
+template <int EX, int NU>
+__device__ __forceinline__ void ex_dot_pair_all(const uint4* __restrict__ p0, const uint4* __restrict__ p1, const float* sq, uint32_t gl,
+                                                float& s0, float& s1) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    uint4 a[NU], b[NU];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) { a[j] = p0[j * 16]; b[j] = p1[j * 16]; }
+    f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const uint32_t w0[5] = {a[j].x, a[j].y, a[j].z, a[j].w, 0u}, w1[5] = {b[j].x, b[j].y, b[j].z, b[j].w, 0u};
+        const float* qj = sq + j * CPU * 16 + gl;
+#pragma unroll
+        for (int k = 0; k < CPU; ++k) {
+            const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+            uint32_t c0, c1;
+            if (sh + EX <= 32) { c0 = (w0[idx] >> sh) & mask; c1 = (w1[idx] >> sh) & mask; }
+            else {
+                c0 = ((w0[idx] >> sh) | (w0[idx + 1] << (32 - sh))) & mask;
+                c1 = ((w1[idx] >> sh) | (w1[idx + 1] << (32 - sh))) & mask;
+            }
+            const float qv = qj[16 * k]; // (zero beyond D: the padded code slots are zero as well, 0 * 0 + s == s)
+            const f32x2 cf = {(float)c0, (float)c1}, qq = {qv, qv};
+            acc = __builtin_elementwise_fma(cf, qq, acc);
+            if (k % RBQ_PAIR_PIN == RBQ_PAIR_PIN - 1 || k == CPU - 1) asm volatile("" : "+v"(acc) :: "memory");
+        }
+    }
+    s0 = acc.x; s1 = acc.y;
+}
+
+// Decode halves of the above for callers that request the units themselves and do other work while they are in flight
+// (k_scanw): `a` / `b` = the NU units of the two vectors; NCODES = D / 16 codes per lane (the tail of the last unit is zero padding
+// and is not decoded).
+template <int EX, int NU, int NCODES>
+__device__ __forceinline__ void ex_dot_pair_regs(const uint4* a, const uint4* b, const float* sq, uint32_t gl, float& s0, float& s1) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        uint4 wa = a[j], wb = b[j];
+        const float* qj = sq + j * CPU * 16 + gl;
+#pragma unroll
+        for (int k = 0; k < CPU; ++k) {
+            if (j * CPU + k < NCODES) {
+                const uint32_t w0[5] = {wa.x, wa.y, wa.z, wa.w, 0u}, w1[5] = {wb.x, wb.y, wb.z, wb.w, 0u};
+                const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+                uint32_t c0, c1;
+                if (sh + EX <= 32) { c0 = (w0[idx] >> sh) & mask; c1 = (w1[idx] >> sh) & mask; }
+                else {
+                    c0 = ((w0[idx] >> sh) | (w0[idx + 1] << (32 - sh))) & mask;
+                    c1 = ((w1[idx] >> sh) | (w1[idx + 1] << (32 - sh))) & mask;
+                }
+                const float qv = qj[16 * k];
+                const f32x2 cf = {(float)c0, (float)c1}, qq = {qv, qv};
+                acc = __builtin_elementwise_fma(cf, qq, acc);
+                // the FMA chain is serial, so the scheduler hoists the (independent) decode of every later code above it — a
+                // hundred live registers; passing the code words through the pin as well keeps the decode within a stretch
+                if (k % RBQ_PAIR_PIN == RBQ_PAIR_PIN - 1 || k == CPU - 1 || j * CPU + k == NCODES - 1)
+                    asm volatile("" : "+v"(acc), "+v"(wa.x), "+v"(wa.y), "+v"(wa.z), "+v"(wa.w), "+v"(wb.x), "+v"(wb.y), "+v"(wb.z), "+v"(wb.w) :: "memory");
+            }
+        }
+    }
+    s0 = acc.x; s1 = acc.y;
+}
+template <int EX, int NU, int NCODES>
+__device__ __forceinline__ float ex_dot_one_regs(const uint4* a, const float* sq, uint32_t gl) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const uint32_t w0[5] = {a[j].x, a[j].y, a[j].z, a[j].w, 0u};
+        const float* qj = sq + j * CPU * 16 + gl;
+#pragma unroll
+        for (int k = 0; k < CPU; ++k) {
+            if (j * CPU + k < NCODES) {
+                const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+                uint32_t c0;
+                if (sh + EX <= 32) c0 = (w0[idx] >> sh) & mask;
+                else c0 = ((w0[idx] >> sh) | (w0[idx + 1] << (32 - sh))) & mask;
+                acc = fmaf((float)c0, qj[16 * k], acc);
+                if (k % RBQ_PAIR_PIN == RBQ_PAIR_PIN - 1 || k == CPU - 1 || j * CPU + k == NCODES - 1) asm volatile("" : "+v"(acc) :: "memory");
+            }
+        }
+    }
+    return acc;
+}
+
 // ---- the same BinaryHeap held in the replay wave's registers ------------------------------------------------
 // Entry i lives in lane i % 64 of register i / 64; TR registers hold 64*TR entries (the heap is one entry over top_k
 // between a push and the pop that follows, so top_k <= 64*TR - 1: 63 with one register, 255 with four).
@@ -806,10 +904,10 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
         const uint32_t sl0 = q_slot[e0], sl1 = q_slot[e1];
         const uint4* p0 = reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl0 * exb) + gl;
         const uint4* p1 = reinterpret_cast<const uint4*>(P.ex_codes + (size_t)sl1 * exb) + gl;
-        float fa0 = P.f_add_ex[sl0], fr0 = P.f_rescale_ex[sl0], fa1 = P.f_add_ex[sl1], fr1 = P.f_rescale_ex[sl1];
-        asm volatile("" : "+v"(fa0), "+v"(fr0), "+v"(fa1), "+v"(fr1)); // issue the loads here
+        // (no register pin on the four factor loads: it made the wave WAIT for them before the code units were even requested)
+        const float fa0 = P.f_add_ex[sl0], fr0 = P.f_rescale_ex[sl0], fa1 = P.f_add_ex[sl1], fr1 = P.f_rescale_ex[sl1];
         float sa, sb;
-        if (kDualN) ex_dot_pair_units<(EX ? EX : 2), (kDualN ? (int)kNU : 1)>(p0, p1, s_q, gl, sa, sb);
+        if (kDualN) ex_dot_pair_all<(EX ? EX : 2), (kDualN ? (int)kNU : 1)>(p0, p1, s_q, gl, sa, sb);
         else {
             const uint4 u0 = p0[0], u1 = p1[0];
             if (EX == 6) ex_dot_pair1<6>(u0, u1, s_q, gl, D / 16, sa, sb);

@@ -101,6 +101,7 @@ struct ScanParams {
     uint32_t* heap_ws;            // null, or [nq][2 * (top_k + 1)] words: the exact heap in global memory (top_k beyond the LDS)
     const uint32_t* dead_skipped; // [nq] vectors of probed lists that the probe selection proved skipped as a whole (they
                                   // never enter the stream; diagnostics add them to skipped_by_lower_bound), or null
+    uint32_t wave_kernel;         // 1: k_scanw (one wave per query, scanw.hpp) where it serves the call; 0: k_scan (one workgroup per query)
 };
 // traffic counters kept while a profile is open (rbq_profile_begin/end); [0] is written by the select kernels
 enum { kProfVectorsProbed = 0, kProfCodeBlocks = 1, kProfMetaBlocks = 2, kProfStreamEntries = 3, kProfExEvals = 4,

@@ -4,6 +4,10 @@ import sys
 import numpy as np
 import pytest
 
+# the test harness is the host here: 16 hardware queues for the multi-stream tests, as INTEGRATION.md G tells a host to arrange
+# (librbq.so itself no longer touches the environment; rbq_process_defaults() is its opt-in equivalent)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -102,19 +102,22 @@ def test_missing_hip_library_fails_loudly(monkeypatch):
         ix.lib()
 
 
-def test_library_asks_for_16_hardware_queues_unless_the_host_chose():
-    """librbq.so's load-time constructor sets GPU_MAX_HW_QUEUES=16 (read by the HIP runtime when it initialises) only when the host
-    has not set the variable itself."""
+def test_library_leaves_the_environment_alone_and_process_defaults_is_opt_in():
+    """Loading librbq.so does not touch the process environment (ADVICE r4: the load-time constructor of round 4 is gone);
+    rbq_process_defaults() sets GPU_MAX_HW_QUEUES=16 only when the host has not chosen a value itself."""
     import subprocess
     import sys
     code = ("import ctypes, os, sys\n"
             "lib = ctypes.CDLL(%r)\n"
             "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
-            "print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())\n") % ix.LIB_PATH
+            "print('loaded:' + (libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())\n"
+            "print('rc:%%d' %% lib.rbq_process_defaults())\n"
+            "print('after:' + (libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())\n") % ix.LIB_PATH
     for preset, want in ((None, "16"), ("8", "8")):
         env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
         if preset:
             env["GPU_MAX_HW_QUEUES"] = preset
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr[-1500:]
-        assert out.stdout.strip().splitlines()[-1] == want, (preset, out.stdout)
+        lines = out.stdout.strip().splitlines()[-3:]
+        assert lines == ["loaded:" + (preset or ""), "rc:0", "after:" + want], (preset, out.stdout)

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 out=rabitq-rs_amd/csrc/variants; mkdir -p $out/obj_$name
-for u in k_scan k_scan2 k_query k_build rbq_api; do
+for u in k_scan k_scan2 k_scanw k_scanw2 k_query k_build rbq_api; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -Wno-unused-function \
     -I include "$@" -c rabitq-rs_amd/csrc/device/$u.hip -o $out/obj_$name/$u.o &
 done

@@ -35,3 +35,18 @@ for t, dl in pts:
     c += dl
 tot = sum(hist.values())
 print("kernels in flight:", {k: round(v / tot, 3) for k, v in sorted(hist.items())})
+
+# per stream: idle time between the end of a kernel and the start of the next one of the same stream
+bys = collections.defaultdict(list)
+for e in win:
+    bys[e[3]].append(e)
+gaps = collections.defaultdict(list)
+for s_, evs in bys.items():
+    evs.sort()
+    for x, y in zip(evs, evs[1:]):
+        gaps[x[2] + '->' + y[2]].append((y[0] - x[1]) / 1e3)
+for k, v in sorted(gaps.items()):
+    v.sort()
+    print("gap %-20s mean %.1f us  p50 %.1f  p90 %.1f  n %d" % (k, sum(v) / len(v), v[len(v) // 2], v[int(len(v) * 0.9)], len(v)))
+busy = sum(e[1] - e[0] for e in win)
+print("sum of kernel durations / window = %.2f (mean kernels in flight)" % (busy / (t1 - t0)))
