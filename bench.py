@@ -59,6 +59,15 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+# HBM bytes per bound-off k_scan launch of the HEADLINE configuration from the committed PMC pass of this build (FETCH_SIZE x 2 on
+# gfx950, its own rocprofv3 run: profiles/r5/summary_headline.md).  PMC counters cannot be read inside a normal bench run, so
+# roofline.traffic carries this figure (and says where it comes from); tools/profile_round.sh regenerates it.
+PMC_TRAFFIC = {"bytes": None, "source": None}
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r5", "pmc_traffic.json")) as _f:
+        PMC_TRAFFIC = json.load(_f)
+except Exception:  # noqa: BLE001
+    pass
 HEADLINE = dict(n=1_000_000, dim=960, nlist=4096, nprobe=128, bits=7, metric=0, batch=1024, top_k=10)
 # BASELINE.json `configs` by name; cfg3 = the headline; the reference's own benchmark setting is top_k = 100
 # (examples/recall_qps_sweep.rs:111,120,225-237)
@@ -617,7 +626,7 @@ def main():
         req, parts = traffic_of(c, D, Dc, ex_bits, steps)
         alg = prof["algorithmic_bytes"] / max(steps, 1)
         ms = prof["scan_ms"]
-        return {"kernel": "k_scan (product configuration: exact block-level bound ON)",
+        return {"kernel": "the scan of the product configuration (exact block-level bound ON; which kernel: regime.scan_kernel)",
                 "avg_launch_ms": ms, "launches": prof["scan_launches"],
                 "algorithmic_bytes_per_launch": alg, "bytes_requested_per_launch": req, "bytes_requested_by_array": parts,
                 "algorithmic_bytes_are": "of the APPROXIMATE probe set (the lazy selection resolves the boundary zone of the nprobe-th score only "
@@ -784,19 +793,36 @@ def main():
         idx.set_option("block_bound", 0)
         _, _, p2 = run_timed(idx, q_all, a.nprobe, n_rf, 2, 1, gather=False)
         ids_off = search_ids(idx, q_all[:2], a.nprobe)
+        # the same streaming configuration through the wave-per-query kernel (k_scanw: what serves the PRUNED regime of this batch
+        # size; the library picks k_scan when every block is streamed)
+        wave = None
+        try:
+            idx.set_option("scan_wave", 1)
+            _, _, p3 = run_timed(idx, q_all, a.nprobe, n_rf, 2, 1, gather=False)
+            ids_w = search_ids(idx, q_all[:2], a.nprobe)
+            ach3 = p3["algorithmic_bytes"] / n_rf / (p3["scan_ms"] * 1e-3) / 1e9
+            wave = {"kernel": "k_scanw (one wave per query)", "achieved": ach3, "frac": ach3 / HBM_PEAK_GBS, "avg_launch_ms": p3["scan_ms"],
+                    "launches": p3["scan_launches"], "ids_identical_to_product_configuration": bool(np.array_equal(ids_w, ids_all[:2]))}
+        except Exception as e:  # noqa: BLE001
+            wave = {"error": str(e)[:200]}
+        idx.set_option("scan_wave", -1)
         idx.set_option("block_bound", 1)
         alg2 = p2["algorithmic_bytes"] / n_rf
         req2, _ = traffic_of(p2["counters"], D, Dc, ex_bits, n_rf)
         ach = alg2 / (p2["scan_ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        roofline = {"bound": "hbm", "kernel": "k_scan (one workgroup per query: the kernel the library runs when every probed block is streamed)",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get("bytes") if is_headline else None,
+                    "traffic_from": PMC_TRAFFIC.get("source") if is_headline else None,
                     "algorithmic_bytes_per_launch": alg2, "bytes_requested_per_launch": req2, "avg_launch_ms": p2["scan_ms"],
                     "launches": p2["scan_launches"], "launch_ms": p2["scan_samples_ms"], "ids_identical_to_product_configuration": bool(np.array_equal(ids_off, ids_all[:2])),
+                    "wave_kernel_same_configuration": wave,
                     "configuration": "block-level bound OFF (rbq_debug_set_option block_bound=0): every probed block is streamed, "
                                      "so the algorithmic bytes (SURVEY 8d: sum n_c*(D/8+12)) are the bytes moved; one stream, "
                                      "distinct query batch per launch; HIP events carried by the dispatch packets",
-                    "note": "traffic (PMC) is collected in separate rocprofv3 passes: profiles/r3/; bytes_requested_per_launch is "
-                            "the kernel's own count for the same launches (codes + factor rows + stream + ex codes + LUT)"}
+                    "note": "traffic = FETCH_SIZE x 2 of the committed PMC pass of this build (profiles/r5/summary_headline.md; null when no pass "
+                            "exists for the configuration); bytes_requested_per_launch is the kernel's own count for the same launches "
+                            "(codes + factor rows + stream + ex codes + LUT)"}
         if stage_pass:
             # every stage alone on one stream (no overlap between batches), rotating batches
             stv = torch.cuda.Stream(dev)
@@ -1043,6 +1069,8 @@ def main():
             regime = {"bound": "residency / latency: dependent phases per query keep waves resident while they wait; neither HBM "
                                "(see `pruned`) nor issue slots",
                       "stages": stages_o,
+                      # the product configuration's scan: 64 threads per query = k_scanw (one wave per query), 256 = k_scan
+                      "scan_kernel": ("k_scanw (one wave per query)" if (res.get("scan") or {}).get("threads") == 64 else "k_scan (one workgroup of four waves per query)"),
                       "ms_per_step": step_ms,
                       "sum_of_stage_ms_alone": (sum(v for v in serial["stage_ms"].values()) if serial else None),
                       "overlap_gain": (sum(v for v in serial["stage_ms"].values()) / step_ms if serial else None),
@@ -1121,10 +1149,21 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"synthetic GIST-1M-shaped fvecs ({a.dataset}) {what}",
+        # (the driver's record keeps `config` with its values but cuts strings at 128 characters and keeps only the NAMES of other
+        # top-level objects: the short workload string and the numbers a reader of the one line needs live here)
+        "config": {"workload": f"synthetic {a.dataset} N={a.n} d={a.dim} nlist={a.nlist} {a.bits}-bit {'L2' if a.metric == 0 else 'IP'} nprobe={a.nprobe} "
+                               f"top_k={a.top_k} batch={a.batch}/GPU",
+                   "workload_detail": f"synthetic GIST-1M-shaped fvecs ({a.dataset}) {what}",
+                   "dataset_note": ("mixture_id32 is the FASTEST member of the intrinsic-dimension family {16, 32, 64, 128} (+5-12 % over the "
+                                    "others: `sensitivity`); SURVEY 8d's isotropic recipe caps recall@10 at 0.93: `datasets`") if a.dataset == "mixture_id32" else None,
                    "parallelism": f"index replicated x{world}, queries sharded, RCCL all_gather of top-k",
                    "streams": ns, "distinct_query_batches": NB,
-                   "value_is": "device-resident rate (queries and results in HBM); pcie_inclusive holds the host-buffer rate"},
+                   "scan_kernel": (regime or {}).get("scan_kernel"),
+                   "host_call_queries_per_s": (host_call or {}).get("queries_per_s"),
+                   "host_call_us_per_1024_query_call": ((host_call or {}).get("us_per_call") or {}).get("median"),
+                   "latency_p50_us_1_query": ((latency or {}).get("1") or {}).get("p50_us") if isinstance(latency, dict) else None,
+                   "latency_p50_us_64_queries": ((latency or {}).get("64") or {}).get("p50_us") if isinstance(latency, dict) else None,
+                   "value_is": "device-resident rate (queries and results in HBM); host_call_* = ONE rbq_search_batch call per step"},
         "recall_at_10" if a.top_k == 10 else f"recall_at_{a.top_k}": recall,
         "recall_ok": recall_ok,
         "recall_over_queries": NB * a.batch,

@@ -1093,7 +1093,10 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.mstg = mstg ? 1u : 0u;
     P.prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
-    P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries)) ? 1u : 0u;
+    // scan_wave = 2 (default): the wave-per-query kernel serves the pruned regime of batches large enough to fill the chip with
+    // waves; with the block bound off (every probed block streamed: the roofline configuration) the four-wave kernel streams
+    // at twice its rate and serves the call.  Results are identical either way.
+    P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries && !ix->no_block_bound)) ? 1u : 0u;
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
         int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);

@@ -540,9 +540,14 @@ struct RankRun {
     // Merge the batch `mt` (lane j: lower-bound bits v_lb, refined distance bits v_d, slot v_s) into the run.  `serial`
     // forces the serial decision (exact c_skip/c_ext/c_est: diagnostics).  dk_bits <- bits of the k-th distance once the
     // run is full.  lds_k/lds_s: scratch for top_k entries.  Returns true if an equal key was met.
+    // lazy / amb_min: LAZY TIES (k_scanw).  Equal keys do not end the fast path on the spot: they are ordered by a fixed rule (run
+    // entries below candidates, candidates by lane) and merged like any others; what is recorded is the one thing that can make
+    // the reference's RESULT depend on the layout of its heap later on — an element that LEAVES (or is turned away) with the key of
+    // the maximum that stays: amb_min = the smallest such key.  See k_scanw's final check for why that, plus a look at the final
+    // run for equal neighbours, decides exactly the queries that need the BinaryHeap emulation.
     static __device__ __forceinline__ bool merge_batch(H& h, uint32_t top_k, unsigned long long mt, int v_lb, int v_d, uint32_t v_s,
                                                        uint32_t lane, bool serial, int* lds_k, uint32_t* lds_s, uint32_t& c_skip,
-                                                       uint32_t& c_ext, uint32_t& c_est, int& dk_bits
+                                                       uint32_t& c_ext, uint32_t& c_est, int& dk_bits, const bool lazy, int& amb_min
 #if RBQ_STAMPS == 4
                                                        , unsigned long long* mst
 #define MSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); mst[i] += t_ - mst[3]; mst[3] = t_; } while (0)
@@ -574,11 +579,12 @@ struct RankRun {
             uint32_t cnt = 0;
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
-                const bool gt = s > (r == 0 ? h.hd : h.xd[r]);
+                const int kr = r == 0 ? h.hd : h.xd[r];
+                const bool gt = lazy ? s >= kr : s > kr; // (lazy: a candidate sits ABOVE the run entries of its key; empty lanes hold kHigh)
                 Q[r] += gt ? 1 : 0;
                 cnt += (uint32_t)__popcll(__ballot(gt));
             }
-            QA += s > x ? 1 : 0;
+            QA += (s > x || (lazy && s == x && i > lane)) ? 1 : 0; // (lazy: equal candidates in lane order)
             cB = lane == i ? cnt : cB;
         }
         MSTAMP(0);
@@ -625,7 +631,10 @@ struct RankRun {
                 const int ke = __builtin_amdgcn_readlane(x, (int)j);
                 if (full) {
                     if (ke > tk) continue;
-                    if (ke == tk) { tie = true; continue; }
+                    if (ke == tk) { // turned away with the key of the maximum: which of the two the reference keeps depends on its heap
+                        if (lazy) amb_min = amb_min < tk ? amb_min : tk; else tie = true;
+                        continue;
+                    }
                     if (bt >= am) ++p;
                     else alive &= ~(1ull << (uint32_t)__builtin_ctzll(__ballot(((alive >> lane) & 1ull) && x == am)));
                 } else ++size;
@@ -637,10 +646,14 @@ struct RankRun {
             for (int r = 0; r < TR; ++r) Q[r] = 0;
             QA = 0;
             for (unsigned long long todo = accm; todo; todo &= todo - 1ull) {
-                const int s = __builtin_amdgcn_readlane(x, __builtin_ctzll(todo));
+                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                const int s = __builtin_amdgcn_readlane(x, (int)i);
 #pragma unroll
-                for (int r = 0; r < TR; ++r) Q[r] += s > (r == 0 ? h.hd : h.xd[r]) ? 1 : 0;
-                QA += s > x ? 1 : 0;
+                for (int r = 0; r < TR; ++r) {
+                    const int kr = r == 0 ? h.hd : h.xd[r];
+                    Q[r] += (lazy ? s >= kr : s > kr) ? 1 : 0;
+                }
+                QA += (s > x || (lazy && s == x && i > lane)) ? 1 : 0;
             }
         }
         MSTAMP(1);
@@ -678,7 +691,9 @@ struct RankRun {
                 bool twin = GA >= 0 && GA < (int)evict && x == newmax;
 #pragma unroll
                 for (int r = 0; r < TR; ++r) twin |= G[r] >= 0 && G[r] < (int)evict && (r == 0 ? h.hd : h.xd[r]) == newmax;
-                tie |= __ballot(twin) != 0ull;
+                if (__ballot(twin) != 0ull) {
+                    if (lazy) amb_min = amb_min < newmax ? amb_min : newmax; else tie = true;
+                }
             }
             bool bad = false; // an unwritten position, or a key not above its lower neighbour
 #pragma unroll
@@ -691,7 +706,7 @@ struct RankRun {
                     const int carry = __builtin_amdgcn_readlane(r == 1 ? h.hd : h.xd[r - 1], 63);
                     below = lane == 0 ? carry : below;
                 }
-                bad |= idx < nlen && (kv == kHigh || !(below < kv));
+                bad |= idx < nlen && (kv == kHigh || (lazy ? below > kv : !(below < kv))); // (lazy: equal neighbours are in order)
                 if (r == 0) { h.hd = kv; h.hs = sv; } else { h.xd[r] = kv; h.xs[r] = sv; }
             }
             tie |= __ballot(bad) != 0ull;
@@ -1316,8 +1331,9 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
 #else
                     const bool serial_counts = count_skips;
 #endif
+                    int amb_unused = 0;
                     const bool tie = RankRun<TR>::merge_batch(rh, top_k, bt.mt, bt.v_lb, v_d, v_s, lane, serial_counts,
-                                                              reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk
+                                                              reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk, false, amb_unused
 #if RBQ_STAMPS == 4
                                                               , mst
 #endif

@@ -27,7 +27,10 @@
 namespace rbq {
 
 #ifndef RBQ_SCANW_WAVES
-#define RBQ_SCANW_WAVES 4     // launch-bounds occupancy target (waves per SIMD): 128 VGPRs; the LDS (LUT + query per wave) allows 4 at D = 960
+#define RBQ_SCANW_WAVES 4     // launch-bounds occupancy target (waves per SIMD) of the RankRun instantiations (top_k >= 64): 128 VGPRs
+#endif
+#ifndef RBQ_SCANW_WAVES1
+#define RBQ_SCANW_WAVES1 5    // ... of the top_k < 64 instantiations: 96 VGPRs (they need 84 at D = 960), and 8 KB of LDS per query at D = 960
 #endif
 #ifndef RBQ_W_PREF_FIRST
 #define RBQ_W_PREF_FIRST 0    // 1: the next tile's records are requested BEFORE the first refine round's codes (else behind them)
@@ -47,13 +50,26 @@ namespace rbq {
 #ifndef RBQ_W_WIN_GROW
 #define RBQ_W_WIN_GROW 4
 #endif
-constexpr uint32_t kWQueueCap = 128; // live-block ring (>= RBQ_W_FILL_BELOW - 1 + 64)
-static_assert(RBQ_W_FILL_BELOW - 1 + 64 <= (int)kWQueueCap, "live queue too small");
+// live-block ring and the largest fill window.  60 entries + the 8-word batch list = 512 bytes: at D = 960 / 7 bits a query then needs
+// exactly 8 KB of LDS (LUT 3840 + rotated query 3840 + 512), i.e. 20 waves per compute unit = five per SIMD.
+constexpr uint32_t kWQueueCap = 60;
+constexpr uint32_t kWWinMax = 56;
+static_assert(RBQ_W_FILL_BELOW - 1 + kWWinMax <= kWQueueCap, "live queue too small");
+// rotated query in LDS: the compile-time-dimension kernels decode exactly D / 16 codes per lane (no zero padding behind D needed)
+__host__ __device__ inline uint32_t scanw_qlen(uint32_t D, uint32_t ex_bits, bool compile_time_dim) {
+    if (!ex_bits) return 0u;
+    return (compile_time_dim && ex_w4(D, ex_bits) <= 4u) ? D : ex_qlen(D, ex_bits);
+}
+__host__ __device__ inline bool scanw_compile_time_dim(uint32_t D, uint32_t Dc) {
+    return D == Dc && (D == 128 || D == 256 || D == 384 || D == 512 || D == 768 || D == 960 || D == 1024 || D == 1536);
+}
 
-// LDS carve-up of k_scanw (dynamic only, LUT at byte 0): lut[4Dc] u8 | qrot[ex_qlen] f32 (ex_bits > 0) | queue[kWQueueCap] WorkItem |
-// heap_d[64 TR] f32 | heap_s[64 TR] u32 (final heap-sort of the exact heap; RankRun scatter) | batch[8] u32 (lanes of a round's candidates)
+// LDS carve-up of k_scanw (dynamic only, LUT at byte 0): lut[4Dc] u8 | qrot[scanw_qlen] f32 | queue[kWQueueCap] WorkItem | batch[8] u32
+// (lanes of a round's candidates) | TR > 1 only: heap_d[64 TR] f32 | heap_s[64 TR] u32 (RankRun's scatter; final heap-sort of the exact
+// heap).  TR = 1: the 512 bytes of queue + batch serve the final heap-sort (both are dead by then).
 __host__ __device__ inline size_t scanw_lds_bytes(uint32_t Dc, uint32_t D, uint32_t ex_bits, int tr) {
-    return (size_t)Dc * 4 + (ex_bits ? (size_t)ex_qlen(D, ex_bits) * 4 : (size_t)0) + kWQueueCap * sizeof(WorkItem) + (size_t)tr * 64 * 8 + 32;
+    return (size_t)Dc * 4 + (size_t)scanw_qlen(D, ex_bits, scanw_compile_time_dim(D, Dc)) * 4 + kWQueueCap * sizeof(WorkItem) + 32 +
+           ((tr > 1 || RBQ_W_RANKRUN1) ? (size_t)tr * 64 * 8 : (size_t)0);
 }
 
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -81,16 +97,18 @@ __device__ __forceinline__ float lane_shfl_f32(float v, uint32_t src_lane) {
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.  TR: registers per lane of the
 // top-k (1: top_k <= 63; 2: <= 128; 4: <= 255).  Not served here (k_scan does): MSTG scans, heaps outside the registers.
 template <int DT, int EX, int TR>
-__global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
+__global__ __launch_bounds__(64, (TR == 1 ? RBQ_SCANW_WAVES1 : RBQ_SCANW_WAVES)) void k_scanw(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smraw[];
     const uint32_t Dc = DT ? (uint32_t)DT : P.Dc; // code/LUT dimension (x64)
     const uint32_t D = DT ? (uint32_t)DT : P.D;   // padded_dim (ex codes, rotated query)
     const uint32_t ex_bits = DT ? (uint32_t)EX : P.ex_bits;
-    const uint32_t qlen = ex_bits ? ex_qlen(D, ex_bits) : 0u;
+    const uint32_t qlen = scanw_qlen(D, ex_bits, DT != 0);
     uint8_t* s_lut = smraw;
     float* s_q = reinterpret_cast<float*>(smraw + (size_t)Dc * 4);
     WorkItem* s_queue = reinterpret_cast<WorkItem*>(s_q + qlen);
-    float* heap_d = reinterpret_cast<float*>(s_queue + kWQueueCap); // [64 TR]
+    uint32_t* s_b = reinterpret_cast<uint32_t*>(s_queue + kWQueueCap); // [8] lanes of a refine round's candidates, in order
+    static_assert(kWQueueCap * sizeof(WorkItem) + 32 == 512, "TR = 1: queue + batch list are the 64-entry heap scratch of the final sort");
+    float* heap_d = (TR > 1 || RBQ_W_RANKRUN1) ? reinterpret_cast<float*>(s_b + 8) : reinterpret_cast<float*>(s_queue); // [64 TR]
     uint32_t* heap_s = reinterpret_cast<uint32_t*>(heap_d + 64 * TR);
 
     const uint32_t q = blockIdx.x, lane = threadIdx.x, half = lane >> 5, l32 = lane & 31u;
@@ -162,6 +180,18 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
     if (kRank && fast) RankRun<TR>::clear(rh);
     int bag_dk = 0x7f800000; // RankRun: bits of the k-th distance (valid once the run holds top_k entries)
+    // LAZY TIES.  On the fast path equal distances do not stop the pass; they are kept in a fixed order and two facts are tracked:
+    //   amb_min = the smallest key with which an element ever LEFT the top-k (or was turned away from a full one) while an element of
+    //             the same key stayed — the only moment at which the reference's choice depends on the layout of its BinaryHeap;
+    //   the final run itself (equal neighbours: into_sorted_vec's order of the two is the heap's).
+    // Claim: if the final run has no equal neighbours and its maximum differs from amb_min (or the run is not full), the reference
+    // returns exactly this run.  Proof: the MULTISET of keys in the reference's heap never depends on its layout (push adds a key,
+    // pop removes a maximum key), so its thresholds, skips and pushes are those of the fast path; its heap and the run can differ
+    // only in WHICH of several equal-key elements they hold, i.e. only after an element left while an equal one stayed — with key
+    // K >= every key still inside.  Keys inside only shrink afterwards: if the final maximum is below K, every element of key K has
+    // left both, and the two hold the same elements again; if it equals K, K = amb_min and the check fires.  With the same elements
+    // and no equal neighbours the sorted output is unique.  Otherwise the query is re-run with the BinaryHeap emulation.
+    int amb_min = 0x7fffffff;
     auto cur_distk = [&]() -> float {
         if (fast) return rh.len < top_k ? INFINITY : __int_as_float(!kRank ? SortedRun<TR>::kth(rh.hd, rh.xd, rh.len, top_k) : bag_dk);
         return rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0));
@@ -217,7 +247,7 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
             }
             qcount += (uint32_t)__popcll(lm);
             pos += win;
-            win = win * (uint32_t)RBQ_W_WIN_GROW < 64u ? win * (uint32_t)RBQ_W_WIN_GROW : 64u;
+            win = win * (uint32_t)RBQ_W_WIN_GROW < kWWinMax ? win * (uint32_t)RBQ_W_WIN_GROW : kWWinMax;
             wave_lds_sync();
             WSTAMP_END(st_fill);
         }
@@ -275,7 +305,6 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
         // only shrinks), refines them in parallel and replays them against the running threshold.
         unsigned long long mt = 0ull;
         uint32_t ncol = 0, rank = 0;
-        uint32_t* s_b = heap_s + 64 * TR; // [8] lanes of the taken candidates, in order
         auto collect = [&](uint32_t gmax) __attribute__((always_inline)) {
             WR0();
             mt = 0ull; ncol = 0;
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
                     uint32_t c_skip = 0, c_ext = 0, c_est = 0;
                     int dk = bag_dk;
                     const bool t1 = RankRun<TR>::merge_batch(rh, top_k, mph, __float_as_int(A_lb), __float_as_int(dj), A_slot, lane, count_skips,
-                                                             reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk);
+                                                             reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk, true, amb_min);
                     bag_dk = dk;
                     n_skip_u += c_skip; n_ext += c_ext; n_est += c_est;
                     tie |= t1;
@@ -424,14 +453,16 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)A_slot, (int)j);
                         if (fast) {
                             const int ke = HeapOps::key(dbits);
-                            if (len_s == top_k) {
-                                const int kk2 = HeapOps::key(dk);
+                            const bool was_full = len_s == top_k;
+                            const int kk2 = HeapOps::key(dk);
+                            if (was_full) {
                                 if (ke > kk2) continue;                             // pushed and popped again: no change
-                                if (ke == kk2) { tie = true; continue; }            // which of the equal maxima leaves depends on the heap layout
+                                if (ke == kk2) { amb_min = amb_min < kk2 ? amb_min : kk2; continue; } // turned away with the maximum's key (lazy tie)
                             }
-                            tie |= SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane);
+                            (void)SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane); // (equal keys: side by side)
                             len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
                             dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
+                            if (was_full && HeapOps::key(dk) == kk2) amb_min = amb_min < kk2 ? amb_min : kk2; // the old maximum left, its twin stays
                         } else {
                             rh.push(dbits, slot);
                             if (rh.len > top_k) rh.pop();
@@ -477,6 +508,26 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
         cur = nxt;
         n = n_next;
     }
+    if (fast && !tie) { // the final look of the lazy-tie rule
+        const uint32_t lenf = HeapOps::uni(rh.len);
+        bool eq = false;
+        int maxkey = (int)0x80000000;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const uint32_t i = (uint32_t)r * 64u + lane;
+            const int b = r == 0 ? rh.hd : rh.xd[r];
+            const int kv = kRank ? b : HeapOps::key(b);
+            int below = __builtin_amdgcn_update_dpp((int)0x80000000, kv, 0x138, 0xf, 0xf, false); // wave_shr:1
+            if (r > 0) {
+                const int pb = r == 1 ? rh.hd : rh.xd[r - 1];
+                const int carry = __builtin_amdgcn_readlane(kRank ? pb : HeapOps::key(pb), 63);
+                below = lane == 0 ? carry : below;
+            }
+            eq |= i >= 1u && i < lenf && kv == below;
+            if (lenf && (lenf - 1u) >> 6 == (uint32_t)r) maxkey = __builtin_amdgcn_readlane(kv, (int)((lenf - 1u) & 63u));
+        }
+        tie = __ballot(eq) != 0ull || (lenf == top_k && maxkey == amb_min);
+    }
     if (!(fast && tie)) break;
     if (lane == 0 && P.heap_restarts) atomicAdd(P.heap_restarts, 1u);
     fast = false;
@@ -484,6 +535,7 @@ __global__ __launch_bounds__(64, RBQ_SCANW_WAVES) void k_scanw(ScanParams P) {
     n_skip_l = 0; n_skip_u = 0; n_ext = 0; n_est = 0;
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
     bag_dk = 0x7f800000;
+    amb_min = 0x7fffffff;
   }
 
     // ---- results ----------------------------------------------------------------------------------------------------
