@@ -68,6 +68,8 @@ def lib():
         L.ref_search.restype = C.c_int
         L.ref_search.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64,
                                  vp, vp, vp, vp]
+        L.ref_search_lists.restype = C.c_int
+        L.ref_search_lists.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp]
         L.ref_search_batch.restype = C.c_int
         L.ref_search_batch.argtypes = [vp, vp, f32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp,
                                        C.c_uint64, vp, vp, vp, vp, C.c_int]
@@ -110,6 +112,22 @@ def search_batch(built, queries, top_k, nprobe, filter_words=None, filter_nbits=
     rc = lib().ref_search_batch(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(q), nq, qd, top_k, nprobe,
                                 _p(fw), filter_nbits, _p(ids), _p(scores), _p(counts), _p(diag), nthreads)
     return rc, ids, scores, counts, diag
+
+
+def search_lists(built, query, top_k, nprobe, filter_words=None, filter_nbits=0):
+    """One query: (probe order cids, per probed list the number of its vectors the reference did NOT skip by the lower bound)."""
+    q = np.ascontiguousarray(query, dtype=np.float32)
+    ids = np.zeros(max(top_k, 1), np.uint64)
+    scores = np.zeros(max(top_k, 1), np.float32)
+    cnt = C.c_uint32()
+    cids = np.zeros(built.n_lists, np.uint32)
+    ev = np.zeros(built.n_lists, np.uint32)
+    n = C.c_uint32()
+    fw = np.ascontiguousarray(filter_words, dtype=np.uint32) if filter_words is not None else None
+    rc = lib().ref_search_lists(_addr(built.hdr_ptr), _addr(built.lists_ptr), _p(q), q.shape[0], top_k, nprobe, _p(fw), filter_nbits,
+                                _p(ids), _p(scores), C.byref(cnt), _p(cids), _p(ev), C.byref(n))
+    assert rc == 0, rc
+    return cids[:n.value].copy(), ev[:n.value].copy()
 
 
 def search_naive(built, query, top_k, nprobe):

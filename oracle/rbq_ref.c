@@ -873,6 +873,22 @@ static inline int filter_contains(const uint32_t* words, uint64_t nbits, uint64_
     return (words[i >> 5] >> (i & 31)) & 1;
 }
 
+/* ref_search_lists: the same search; additionally, per probed list in probe order, its id and the number of its vectors that were NOT */
+/* skipped by the lower bound (evaluated: `lower_bound < distk` at their moment, src/ivf.rs:2045-2058) — what the GPU's lazy selection   */
+/* must find to be 0 for every list it drops as a whole (tests: the `lazy_audit` shadow check).                                        */
+static __thread uint32_t* g_trace_cids;
+static __thread uint32_t* g_trace_eval;
+static __thread uint32_t* g_trace_n;
+int ref_search_lists(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
+                     uint32_t top_k, uint32_t nprobe_in, const uint32_t* filter_words, uint64_t filter_nbits,
+                     uint64_t* out_ids, float* out_scores, uint32_t* out_count,
+                     uint32_t* probe_cids, uint32_t* probe_evaluated, uint32_t* n_probed) {
+    g_trace_cids = probe_cids; g_trace_eval = probe_evaluated; g_trace_n = n_probed;
+    int rc = ref_search(h, lists, query, query_dim, top_k, nprobe_in, filter_words, filter_nbits, out_ids, out_scores, out_count, NULL);
+    g_trace_cids = NULL; g_trace_eval = NULL; g_trace_n = NULL;
+    return rc;
+}
+
 int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
                uint32_t top_k, uint32_t nprobe_in, const uint32_t* filter_words, uint64_t filter_nbits,
                uint64_t* out_ids, float* out_scores, uint32_t* out_count, rbq_diag* diag) {
@@ -898,6 +914,7 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
     float lut_delta, lut_sum_vl;
     ref_query_lut(rq, D, lut8, &lut_delta, &lut_sum_vl);
     size_t nprobe = ref_select_probes(h, lists, rq, nprobe_in, cids);
+    if (g_trace_n) *g_trace_n = (uint32_t)nprobe;
 
     if (top_k == 0) return RBQ_OK;
 
@@ -913,6 +930,7 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
         float g_add = h->metric == RBQ_METRIC_L2 ? centroid_dist : -dot_qc;
         float g_error = sqrtf(centroid_dist);
         size_t nb = (cl->n + 31) / 32;
+        if (g_trace_cids) { g_trace_cids[r] = cids[r]; g_trace_eval[r] = 0; }
         for (size_t b = 0; b < nb; ++b) {
             const uint8_t* rec = cl->batch_data + b * stride;
             const float* f_add = (const float*)(rec + D * 4);
@@ -936,6 +954,7 @@ int ref_search(const rbq_header* h, const rbq_list_view* lists, const float* que
                     if (diag) diag->skipped_by_lower_bound++;
                     continue;
                 }
+                if (g_trace_eval) g_trace_eval[r]++;
                 float distance = est[i];
                 if (h->ex_bits > 0) {
                     if (diag) diag->extended_evaluations++;

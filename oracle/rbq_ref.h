@@ -58,6 +58,10 @@ size_t   ref_select_probes(const rbq_header* h, const rbq_list_view* lists, cons
 int      ref_search(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
                     uint32_t top_k, uint32_t nprobe, const uint32_t* filter_words, uint64_t filter_nbits,
                     uint64_t* out_ids, float* out_scores, uint32_t* out_count, rbq_diag* diag);
+int      ref_search_lists(const rbq_header* h, const rbq_list_view* lists, const float* query, uint32_t query_dim,
+                          uint32_t top_k, uint32_t nprobe, const uint32_t* filter_words, uint64_t filter_nbits,
+                          uint64_t* out_ids, float* out_scores, uint32_t* out_count,
+                          uint32_t* probe_cids, uint32_t* probe_evaluated, uint32_t* n_probed); /* per probed list: vectors not skipped */
 int      ref_search_batch(const rbq_header* h, const rbq_list_view* lists, const float* queries, uint64_t nq,
                           uint32_t query_dim, uint32_t top_k, uint32_t nprobe,
                           const uint32_t* filter_words, uint64_t filter_nbits,

@@ -64,6 +64,7 @@ struct RankParams {
 hipError_t launch_rank_exact(const RankParams& p, hipStream_t s);
 hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s);
 
+constexpr uint32_t kAuditCap = 1023; // dead lists exported per query under lazy_audit (a shortlist holds fewer)
 struct SelectParams {
     float* scores;
     uint32_t nq, nlist, nprobe;
@@ -103,6 +104,9 @@ struct SelectParams {
     uint64_t filter_nbits;        // head evaluation — which counts filter-passing vectors only — can bound the k-th distance
     const uint64_t* ids;
     int head_exact;               // 0: Cauchy-Schwarz bound only (round 3)
+    uint32_t* audit_dead;         // null, or (option lazy_audit) [nq][kAuditCap + 1] u32: the number of lists this query's selection dropped as
+                                  // a whole, then their ids — exported WITHOUT changing any decision, with or without diagnostics or a
+                                  // filter, so that a test can ask the oracle what the reference did with exactly those lists
     int fault_dead_all;           // TEST ONLY (debug option lazy_fault_inject, default 0): T_ub := -inf — every list behind the head is
                                   // declared dead whatever its bounds say: a deliberately WRONG selection, so that the
                                   // bound_violations audit can be shown to catch one

@@ -1229,6 +1229,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
             if (P.filter) { // (uniform)
                 T_ub = (G.hx_nv && P.head_exact) ? head_exact_bound(P, G, qc, keys, s_head, s_hgb, s_hn, s_hcn, h, eps, reinterpret_cast<unsigned char*>(rows), qrot, part, hist, q, tid, cost_of) : INFINITY;
                 hx_done = true;
+                if (P.fault_dead_all) T_ub = -INFINITY; // (the test-only fault injection also under a filter: ADVICE r4)
             }
             lazy = T_ub < INFINITY;
             dbg_tub = __float_as_uint(T_ub);
@@ -1337,6 +1338,11 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                             uint32_t less = 0;
                             for (uint32_t j = 0; j < n; ++j) less += ((s_zone[j >> 5] >> (j & 31u)) & 1u) && keys[j] < my ? 1u : 0u;
                             member = less < nprobe - z0;
+                        }
+                        if (dead && P.audit_dead) { // lazy_audit: the dropped lists, for the oracle to look at (no decision changes)
+                            uint32_t* ad = P.audit_dead + (size_t)q * (kAuditCap + 1);
+                            const uint32_t pa = atomicAdd(ad, 1u);
+                            if (pa < kAuditCap) ad[1 + pa] = (uint32_t)keys[i];
                         }
                         if (member && !dead) {
                             m_keep |= 1ull << u;

@@ -114,12 +114,12 @@ struct PinBuf { // page-locked host staging
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window, audit_dead;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     void release() {
         for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
-                          &heap_ws, &key_window})
+                          &heap_ws, &key_window, &audit_dead})
             b->release();
         h_in.release(); h_out.release();
         if (done) (void)hipEventDestroy(done);
@@ -251,6 +251,7 @@ struct Replica {
     bool head_exact = true;  // lazy selection: a bound of the k-th distance from real estimates of the nearest list's first vectors
     bool lazy_filter = true; // search_filtered: lazy selection on the exact head evaluation's bound (filter-passing vectors only)
     bool lazy_fault_inject = false; // TEST ONLY: makes the lazy selection wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
+    bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
                                // workspace of the stream as the last full call wrote it — results are then those of THAT batch (rate probes only)
@@ -1167,6 +1168,12 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     sp.force_fallback = ix->force_rank_fallback ? 1 : 0; sp.bsum = (const BlockSummary*)ix->bsum.p;
     sp.cnorm2 = (const float*)ix->cnorm2.p; sp.lsum = (const BlockSummary*)ix->lsum.p; sp.bsumx = (const BlockSummaryEx*)ix->bsumx.p;
     sp.dead_skipped = (uint32_t*)w->dead_skipped.p; sp.top_k = top_k; sp.ex_bits = ix->ex_bits;
+    sp.audit_dead = nullptr;
+    if (ix->lazy_audit) { // diagnostic: the lists the selection drops as a whole are exported (rbq_debug_copy_workspace "audit_dead")
+        if ((rc = w->audit_dead.ensure(nq * (size_t)(kAuditCap + 1) * 4))) return rc;
+        HIP_TRY(hipMemsetAsync(w->audit_dead.p, 0, nq * (size_t)(kAuditCap + 1) * 4, stream));
+        sp.audit_dead = (uint32_t*)w->audit_dead.p;
+    }
     // lazy selection: not with a filter (filtered vectors are never pushed, so no select-time bound of the k-th distance
     // exists) and not when every probed block is to be streamed
     // (round 4: under a filter the exact head evaluation can still bound the k-th distance — it looks at real vectors and counts
@@ -1908,6 +1915,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_subbatch")) ix->host_subbatch = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
         else if (!std::strcmp(name, "lazy_fault_inject")) ix->lazy_fault_inject = value != 0;
+        else if (!std::strcmp(name, "lazy_audit")) ix->lazy_audit = value != 0;
         else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
         else if (!std::strcmp(name, "lazy_filter")) ix->lazy_filter = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
@@ -1993,6 +2001,7 @@ int rbq_debug_copy_workspace(rbq_index* h, void* hip_stream, const char* name, v
     else if (!std::strcmp(name, "wl")) b = &w->wl;
     else if (!std::strcmp(name, "nvec")) b = &w->nvec;
     else if (!std::strcmp(name, "dead_skipped")) b = &w->dead_skipped;
+    else if (!std::strcmp(name, "audit_dead")) b = &w->audit_dead;
     if (!b || !b->p || bytes > b->cap) return fail(RBQ_INVALID_CONFIG, "unknown buffer or size");
     DeviceGuard g(ix->device);
     HIP_TRY(hipMemcpy(dst, b->p, bytes, hipMemcpyDeviceToHost));

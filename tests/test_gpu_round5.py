@@ -1,0 +1,324 @@
+"""GPU parity tests added in round 5 (`pytest -m gpu`, through the C ABI):
+* k_scanw — the candidate scan with one wave per query (scanw.hpp) — against the oracle AND against k_scan (one workgroup per
+  query), bit for bit, on the configurations of the earlier rounds, at every top-k register class, under filters, with and without
+  diagnostics, on tie-heavy and degenerate inputs (the library picks it for batches >= 128 queries; the tests force it);
+* the LAZY-TIE rule of k_scanw: equal distances that cannot change the result do not restart a query, the ones that can do;
+* `lazy_audit`: the lists the lazy probe selection drops as a whole are exported by the select kernel itself — in the product
+  configuration, without diagnostics, and under a filter — and the oracle is asked what the reference did with exactly those
+  lists: it must have skipped every one of their vectors by the lower bound;
+* a multi-stream stress of the shape that once met a real GPU fault (12 streams x large batches, >= 300 launches);
+* `batch_query` values against the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+import rabitq_rs_amd as rq
+from conftest import build_index, make_dataset
+from test_gpu_parity import RTOL, _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _both_kernels(built, idx, q, top_k, nprobe, filter_words=None, filter_nbits=0):
+    """oracle == k_scan == k_scanw, with and without diagnostics (`_compare` runs both), bit for bit between the two kernels"""
+    idx.set_option("scan_wave", 0)
+    ids0, sc0, cnt0 = _compare(built, idx, q, top_k, nprobe, filter_words, filter_nbits)
+    idx.set_option("scan_wave", 1)
+    ids1, sc1, cnt1 = _compare(built, idx, q, top_k, nprobe, filter_words, filter_nbits)
+    idx.set_option("scan_wave", -1)
+    assert np.array_equal(ids0, ids1) and np.array_equal(cnt0, cnt1)
+    assert np.array_equal(sc0.view(np.uint32), sc1.view(np.uint32))
+    return ids1, sc1, cnt1
+
+
+WAVE_CASES = [
+    # n, dim, nlist, bits, metric, rotator, nq, top_k, nprobe
+    pytest.param(10000, 128, 256, 7, 0, 1, 160, 10, 32, id="cfg1_shape_d128_7bit_L2"),
+    pytest.param(6000, 960, 48, 7, 0, 1, 130, 10, 12, id="gist_shape_d960_7bit_L2"),
+    pytest.param(6000, 960, 48, 3, 1, 1, 130, 10, 16, id="gist_shape_d960_3bit_IP"),
+    pytest.param(5000, 768, 40, 7, 0, 1, 64, 10, 10, id="d768_7bit_L2"),
+    pytest.param(4000, 128, 32, 1, 0, 1, 64, 10, 8, id="d128_1bit_L2"),
+    pytest.param(4000, 128, 32, 1, 1, 1, 64, 10, 8, id="d128_1bit_IP"),
+    pytest.param(4000, 100, 32, 7, 0, 1, 48, 10, 8, id="d100_pad128_7bit_L2"),
+    pytest.param(3000, 200, 24, 3, 0, 1, 48, 5, 24, id="d200_pad256_3bit_all_lists"),
+    pytest.param(3000, 64, 24, 7, 1, 0, 48, 10, 6, id="matrix_rotator_d64_7bit_IP"),
+    pytest.param(3000, 48, 24, 3, 0, 0, 48, 10, 6, id="matrix_rotator_d48_codepad_3bit_L2"),
+    pytest.param(5000, 320, 40, 7, 0, 1, 32, 100, 20, id="d320_runtime_dim_top100"),
+    pytest.param(5000, 512, 40, 7, 0, 1, 32, 10, 20, id="d512_7bit"),
+    pytest.param(3000, 1024, 24, 7, 0, 1, 24, 10, 12, id="d1024_7bit"),
+    pytest.param(1500, 1536, 8, 7, 0, 1, 16, 10, 4, id="d1536_u16_wrap"),
+    pytest.param(2000, 64, 16, 7, 0, 1, 16, 1, 4, id="top1"),
+    pytest.param(600, 16, 13, 1, 0, 1, 30, 5, 6, id="kac_d16_1bit"),
+]
+
+
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,rot,nq,top_k,nprobe", WAVE_CASES)
+def test_wave_kernel_matches_oracle_and_workgroup_kernel(n, dim, nlist, bits, metric, rot, nq, top_k, nprobe):
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot, normalize=(metric == 1),
+                              seed=5000 + dim + bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(5001)
+    far = make_dataset(nq // 2, dim, max(nlist // 4, 1), 5002, normalize=(metric == 1))
+    near = data[rng.choice(n, nq - nq // 2, replace=False)] + 0.03 * rng.standard_normal((nq - nq // 2, dim)).astype(np.float32)
+    if metric == 1:
+        near /= np.linalg.norm(near, axis=1, keepdims=True)
+    q = np.ascontiguousarray(np.concatenate([far, near]), dtype=np.float32)
+    _both_kernels(built, idx, q, top_k, nprobe)
+    idx.close()
+
+
+@pytest.mark.parametrize("top_k", [1, 2, 9, 10, 31, 62, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 300])
+def test_wave_kernel_at_every_top_k_register_class(top_k):
+    """k_scanw keeps the top-k in 1 / 2 / 4 registers per lane (top_k <= 63 / 127 / 255); beyond that (and for instantiations
+    that would spill registers) the library runs k_scan: every class against the oracle, ties included."""
+    base = make_dataset(2500, 128, 8, 61)
+    data = np.concatenate([base, base[:400]], axis=0)  # 400 exact duplicates: bit-identical distances
+    _, built = build_index(nlist=20, total_bits=7, data=data, dim=128)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = np.ascontiguousarray(np.concatenate([base[:24], make_dataset(24, 128, 8, 62)]))
+    _both_kernels(built, idx, q, top_k, 10)
+    idx.close()
+
+
+def test_wave_kernel_filtered_search():
+    data, built = build_index(n=9000, dim=128, nlist=64, total_bits=7, seed=71)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = np.ascontiguousarray(data[:150] + np.float32(0.01))
+    for keep in (2, 10):
+        allowed = np.arange(0, 9000, keep)
+        nbits = 9000
+        words = np.zeros((nbits + 31) // 32, np.uint32)
+        np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+        _both_kernels(built, idx, q, 10, 24, words, nbits)
+    idx.close()
+
+
+def test_wave_kernel_degenerate_queries_and_nonfinite_factors():
+    """NaN / Inf / zero / huge queries beside ordinary ones (inner product: the NaN lower bound that is never skipped), and
+    non-finite factors in the index."""
+    for metric in (0, 1):
+        data, built = build_index(n=5000, dim=128, nlist=32, total_bits=7, metric=metric, normalize=(metric == 1), seed=81 + metric)
+        idx = rq.IvfRabitqIndex.from_built(built)
+        q = make_dataset(140, 128, 8, 82, normalize=(metric == 1))
+        q[0, :] = np.nan; q[1, 3] = np.nan; q[2, :] = np.inf; q[3, 5] = -np.inf; q[4, :] = 0.0; q[5, :] = -0.0
+        q[6, :] = 0.0; q[6, 7] = 1.0; q[7, :] = 1e-30; q[8, :] = 1e30; q[9, :] = 3e38
+        _both_kernels(built, idx, np.ascontiguousarray(q), 10, 12)
+        idx.close()
+
+
+def test_lazy_ties_restart_only_ambiguous_queries():
+    """k_scanw's lazy-tie rule (scanw.hpp).  Index = distinct vectors + a block of exact duplicates:
+    * a query whose top-k CONTAINS a duplicated pair has two equal neighbours in its final run: it must be re-run with the
+      BinaryHeap emulation (and equal the oracle);
+    * with top_k = 1 an equal pair can matter only at the boundary (one stays, its twin is turned away);
+    * queries far from every duplicate meet equal distances only among candidates that all leave again: no restart.
+    In every case the results equal the oracle's and k_scan's (which restarts on every equality it meets)."""
+    base = make_dataset(3000, 64, 6, 91)
+    dup = base[:300]
+    data = np.concatenate([base, dup, dup], axis=0)  # vectors 0..299 exist three times
+    _, built = build_index(nlist=16, total_bits=7, data=data, dim=64)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q_dup = np.ascontiguousarray(base[:64])            # nearest neighbours = the triplicated vectors themselves
+    q_far = np.ascontiguousarray(base[1500:1564] + np.float32(0.02))
+    for q, top_k in ((q_dup, 10), (q_dup, 1), (q_far, 10), (q_far, 100)):
+        _both_kernels(built, idx, q, top_k, 8)
+    # restarts: count them for the two kernels on the far queries (no diagnostics: the product path)
+    idx.set_option("scan_wave", 0)
+    r0 = idx.heap_restarts(); idx.batch_search_raw(np.tile(q_far, (3, 1)), rq.SearchParams(10, 8)); eager = idx.heap_restarts() - r0
+    idx.set_option("scan_wave", 1)
+    r0 = idx.heap_restarts(); idx.batch_search_raw(np.tile(q_far, (3, 1)), rq.SearchParams(10, 8)); lazy = idx.heap_restarts() - r0
+    r0 = idx.heap_restarts(); idx.batch_search_raw(np.tile(q_dup, (3, 1)), rq.SearchParams(10, 8)); lazy_dup = idx.heap_restarts() - r0
+    idx.set_option("scan_wave", -1)
+    assert lazy <= eager, (lazy, eager)
+    assert lazy_dup >= 3 * 32, lazy_dup  # duplicated neighbours inside the top-k: these queries DO need the heap
+    idx.close()
+
+
+# ---- lazy_audit -----------------------------------------------------------------------------------------------------------
+def _audit(idx, built, q, top_k, nprobe, words=None, nbits=0):
+    """one device-entry call WITHOUT diagnostics (the product path) with lazy_audit on; returns per query the list ids the
+    selection dropped as a whole, and how many vectors of each the REFERENCE evaluated (oracle.search_lists)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    nq, dim = q.shape
+    qd = torch.from_numpy(q).to(dev)
+    d_ids = torch.zeros(nq, top_k, dtype=torch.int64, device=dev)
+    d_sc = torch.zeros(nq, top_k, dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros(nq, dtype=torch.int32, device=dev)
+    d_f = torch.from_numpy(words.view(np.int32)).to(dev) if words is not None else None
+    st = torch.cuda.Stream(dev)
+    torch.cuda.synchronize(dev)
+    idx.set_option("lazy_audit", 1)
+    idx.search_batch_device(qd.data_ptr(), nq, dim, top_k, nprobe, d_ids.data_ptr(), d_sc.data_ptr(), d_cnt.data_ptr(),
+                            stream=st.cuda_stream, d_filter=d_f.data_ptr() if d_f is not None else None, filter_nbits=nbits)
+    torch.cuda.synchronize(dev)
+    aud = idx.debug_copy_workspace(st.cuda_stream, "audit_dead", np.empty((nq, 1024), np.uint32))
+    idx.set_option("lazy_audit", 0)
+    idx.release_stream(st.cuda_stream)
+    dropped_lists, violations = 0, 0
+    for i in range(nq):
+        nd = int(aud[i, 0])
+        assert nd <= 1023
+        dead = set(int(c) for c in aud[i, 1:1 + nd])
+        cids, ev = oracle.search_lists(built, q[i], top_k, nprobe, words, nbits)
+        evaluated = {int(c): int(e) for c, e in zip(cids, ev)}
+        dropped_lists += len(dead & set(evaluated))
+        violations += sum(evaluated.get(c, 0) for c in dead)
+    return d_ids.cpu().numpy().view(np.uint64), dropped_lists, violations
+
+
+AUDIT_CASES = [
+    pytest.param(40000, 128, 256, 7, 0, 10, 64, id="d128_7bit_L2"),
+    pytest.param(30000, 960, 128, 7, 0, 10, 48, id="d960_7bit_L2"),
+    pytest.param(30000, 960, 128, 3, 1, 10, 64, id="d960_3bit_IP"),
+    pytest.param(40000, 128, 256, 7, 0, 100, 64, id="d128_top100"),
+]
+
+
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,top_k,nprobe", AUDIT_CASES)
+def test_lazy_audit_product_path_and_filtered_path(n, dim, nlist, bits, metric, top_k, nprobe):
+    """The lists the lazy selection drops — in the NO-diagnostics path and in the FILTERED path, which the diagnostics-difference
+    audit of round 4 could not see — are lists whose every vector the reference skipped by the lower bound."""
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, normalize=(metric == 1), seed=940 + dim + bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(941)
+    nq = 40
+    q = data[rng.choice(n, nq, replace=False)] + 0.05 * rng.standard_normal((nq, dim)).astype(np.float32)
+    if metric == 1:
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    rc, oids, _, _, _ = oracle.search_batch(built, q, top_k, nprobe)
+    ids, dropped, viol = _audit(idx, built, q, top_k, nprobe)
+    assert np.array_equal(ids, oids)
+    assert dropped > 0, "in-distribution queries on centred data: the lazy selection must drop lists"
+    assert viol == 0, f"{viol} vectors of dropped lists were evaluated by the reference"
+    # under a filter (half of the ids pass): the bound comes from the exact head evaluation alone
+    allowed = np.arange(0, n, 2)
+    words = np.zeros((n + 31) // 32, np.uint32)
+    np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+    rc, oids, _, _, _ = oracle.search_batch(built, q, top_k, nprobe, words, n)
+    ids, dropped_f, viol = _audit(idx, built, q, top_k, nprobe, words, n)
+    assert np.array_equal(ids, oids)
+    assert viol == 0, f"filtered: {viol} vectors of dropped lists were evaluated by the reference"
+    if top_k <= 10:
+        assert dropped_f > 0, "the filtered lazy selection dropped nothing"
+    idx.close()
+
+
+def test_lazy_audit_detects_a_loosened_bound_also_under_a_filter():
+    """Fault injection (option lazy_fault_inject: every list behind the head is declared dead whatever its bounds say): the audit
+    must fire — without diagnostics, and under a filter (the fault used to be overwritten there)."""
+    n, dim = 30000, 128
+    data, built = build_index(n=n, dim=dim, nlist=200, total_bits=7, seed=951)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(952)
+    q = np.ascontiguousarray(data[rng.choice(n, 32, replace=False)] + 0.05 * rng.standard_normal((32, dim)).astype(np.float32))
+    allowed = np.arange(0, n, 2)
+    words = np.zeros((n + 31) // 32, np.uint32)
+    np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
+    idx.set_option("lazy_fault_inject", 1)
+    _, _, viol = _audit(idx, built, q, 10, 64)
+    _, _, viol_f = _audit(idx, built, q, 10, 64, words, n)
+    idx.set_option("lazy_fault_inject", 0)
+    assert viol > 0 and viol_f > 0, (viol, viol_f)
+    _, _, viol = _audit(idx, built, q, 10, 64)
+    _, _, viol_f = _audit(idx, built, q, 10, 64, words, n)
+    assert viol == 0 and viol_f == 0
+    idx.close()
+
+
+# ---- stress ----------------------------------------------------------------------------------------------------------------
+def test_twelve_streams_of_large_batches_match_single_stream_bits():
+    """12 streams x 4096-query batches of in-distribution queries, 312 launches, every result compared with the single-stream
+    bits (the shape of the bench run in which round 4's select-kernel race showed as a GPU memory fault; both scan kernels)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, dim, nb, bs, ns = 60000, 128, 6, 4096, 12
+    data, built = build_index(n=n, dim=dim, nlist=256, total_bits=7, seed=961)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    rng = np.random.default_rng(962)
+    q = data[rng.choice(n, nb * bs, replace=True)] + 0.05 * rng.standard_normal((nb * bs, dim)).astype(np.float32)
+    qd = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(dev).view(nb, bs, dim)
+    top_k, nprobe = 10, 64
+    ref = []
+    one = torch.cuda.Stream(dev)
+    for b in range(nb):
+        o = (torch.zeros(bs, top_k, dtype=torch.int64, device=dev), torch.zeros(bs, top_k, dtype=torch.float32, device=dev),
+             torch.zeros(bs, dtype=torch.int32, device=dev))
+        idx.search_batch_device(qd[b].data_ptr(), bs, dim, top_k, nprobe, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), stream=one.cuda_stream)
+        one.synchronize()
+        ref.append((o[0].cpu().numpy().copy(), o[1].cpu().numpy().view(np.uint32).copy(), o[2].cpu().numpy().copy()))
+    # a sample against the oracle
+    rc, oids, _, _, _ = oracle.search_batch(built, q[:256], top_k, nprobe)
+    assert np.array_equal(ref[0][0][:256].view(np.uint64), oids)
+    streams = [torch.cuda.Stream(dev) for _ in range(ns)]
+    outs = [(torch.zeros(bs, top_k, dtype=torch.int64, device=dev), torch.zeros(bs, top_k, dtype=torch.float32, device=dev),
+             torch.zeros(bs, dtype=torch.int32, device=dev)) for _ in range(ns)]
+    launches = 0
+    for rnd in range(26):
+        for s in range(ns):
+            b = (rnd * ns + s) % nb
+            o = outs[s]
+            idx.search_batch_device(qd[b].data_ptr(), bs, dim, top_k, nprobe, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                    stream=streams[s].cuda_stream)
+            launches += 1
+        torch.cuda.synchronize(dev)
+        for s in range(ns):
+            b = (rnd * ns + s) % nb
+            assert np.array_equal(outs[s][0].cpu().numpy(), ref[b][0]), (rnd, s)
+            assert np.array_equal(outs[s][1].cpu().numpy().view(np.uint32), ref[b][1]), (rnd, s)
+            assert np.array_equal(outs[s][2].cpu().numpy(), ref[b][2]), (rnd, s)
+    assert launches >= 300
+    for st in streams + [one]:
+        idx.release_stream(st.cuda_stream)
+    idx.close()
+
+
+def test_caller_threads_with_the_wave_kernel():
+    """four caller threads x rbq_search_batch (host buffers) on one handle, batches large enough for k_scanw"""
+    data, built = build_index(n=20000, dim=128, nlist=128, total_bits=7, seed=971)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    qs = [np.ascontiguousarray(data[i * 700:(i + 1) * 700] + np.float32(0.01)) for i in range(4)]
+    want = [oracle.search_batch(built, q, 10, 32)[1] for q in qs]
+    errs = []
+
+    def work(t):
+        for _ in range(6):
+            ids, _, _, _ = idx.batch_search_raw(qs[t], rq.SearchParams(10, 32))
+            if not np.array_equal(ids, want[t]):
+                errs.append(t)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    idx.close()
+
+
+# ---- the Python facade's values ---------------------------------------------------------------------------------------------
+def test_batch_query_values_match_the_oracle():
+    """`batch_query` (src/python_bindings.rs:593-665): per query a (count, 2) f32 array [id as f32, score] — the VALUES against the
+    oracle (ids exactly as `id as f32`, scores at 1e-4, short counts when fewer than k candidates survive)."""
+    data, built = build_index(n=4000, dim=96, nlist=40, total_bits=7, seed=981)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    q = make_dataset(20, 96, 10, 982)
+    for top_k, nprobe, words in ((10, 8, None), (50, 1, None)):
+        rc, oids, osc, ocnt, _ = oracle.search_batch(built, q, top_k, nprobe)
+        out = idx.batch_query(q, top_k, nprobe)
+        assert len(out) == len(q)
+        for i, a in enumerate(out):
+            c = int(ocnt[i])
+            assert a.dtype == np.float32 and a.shape == (c, 2)
+            assert np.array_equal(a[:, 0], oids[i, :c].astype(np.float32))
+            np.testing.assert_allclose(a[:, 1], osc[i, :c], rtol=RTOL, atol=0)
+    # short counts: one tiny list probed, top_k larger than it holds
+    sizes = built.list_sizes()
+    assert any(int(ocnt[i]) < 50 for i in range(len(q))) or int(sizes.min()) >= 50
+    # ids beyond 2^24 are not exactly representable in f32: the facade must round them exactly as `as f32` does
+    big = np.array([16777217, 16777219, 4294967295], np.uint64)
+    assert np.array_equal(big.astype(np.float32), np.array([16777216.0, 16777220.0, 4294967296.0], np.float32))
+    idx.close()
