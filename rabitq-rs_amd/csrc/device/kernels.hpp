@@ -53,28 +53,28 @@ __device__ __forceinline__ float block_lbmin(const BlockSummary& bs, float g_add
 //     (each operation contributes at most 6e-8 of its operands), magnitudes bounded through the all-codes ranges.
 // +inf when anything is not finite (such a block proves nothing).
 __device__ __forceinline__ float block_ub(const BlockSummary& bs, const BlockSummaryEx& bx, float g_add, float g_err,
-                                          const QueryConsts& qc, uint32_t D, uint32_t ex_bits) {
+                                          const QueryConsts& qc, uint32_t D, uint32_t ex_bits, const SlackMul sm = SlackMul()) {
     const float ipA = fmaf(qc.delta, qc.amin, qc.sum_vl), ipB = fmaf(qc.delta, qc.amax, qc.sum_vl);
     const float tmax = fmaxf(fabsf(ipA + qc.k1x), fabsf(ipB + qc.k1x));
-    const float ge = g_err * 1.0001f;
-    const float E_ip = (float)D * 0.125f * qc.delta * 1.01f + 1e-4f * qc.q1norm + 1e-6f * (fabsf(qc.sum_vl) + qc.delta * qc.amax);
+    const float ge = g_err * (1.0f + sm.ge * 1e-4f);
+    const float E_ip = sm.eip * ((float)D * 0.125f * qc.delta * 1.01f + 1e-4f * qc.q1norm + 1e-6f * (fabsf(qc.sum_vl) + qc.delta * qc.amax));
     const float fres_abs = fmaxf(fabsf(bs.fres_min), fabsf(bs.fres_max)), fadd_abs = fmaxf(fabsf(bs.fadd_min), fabsf(bs.fadd_max));
     float est_hi = bx.S1 + g_add;
     est_hi += bx.B1 * ge;
     est_hi += fres_abs * E_ip;
-    est_hi += 1e-5f * (fadd_abs + fabsf(g_add) + fres_abs * tmax + fabsf(bx.S1) + bx.B1 * ge);
+    est_hi += sm.est * 1e-5f * (fadd_abs + fabsf(g_add) + fres_abs * tmax + fabsf(bx.S1) + bx.B1 * ge);
     const float ferr_abs = fmaxf(fabsf(bs.ferr_min), fabsf(bs.ferr_max));
-    const float lb_hi = est_hi + fmaxf(-bs.ferr_min, 0.0f) * ge + 1e-5f * ferr_abs * ge; // lb = est - f_error * g_err
+    const float lb_hi = est_hi + fmaxf(-bs.ferr_min, 0.0f) * ge + sm.lb * 1e-5f * ferr_abs * ge; // lb = est - f_error * g_err
     float d_hi = est_hi; // ex_bits == 0: distance = est
     if (ex_bits) {
         const float cmax = (float)((1u << ex_bits) - 1u);
         const float uA = qc.scale * ipA + qc.exlo + qc.kbx, uB = qc.scale * ipB + qc.exhi + qc.kbx;
         const float umax = fmaxf(fabsf(uA), fabsf(uB));
-        const float E_t = qc.scale * E_ip + 1e-3f * cmax * qc.q1norm;
+        const float E_t = qc.scale * E_ip + sm.et * 1e-3f * cmax * qc.q1norm;
         d_hi = bx.S + g_add;
         d_hi += bx.B * ge;
         d_hi += bx.fres_ex_abs * E_t;
-        d_hi += 1e-5f * (bx.fadd_ex_abs + fabsf(g_add) + bx.fres_ex_abs * umax + fabsf(bx.S) + bx.B * ge);
+        d_hi += sm.dist * 1e-5f * (bx.fadd_ex_abs + fabsf(g_add) + bx.fres_ex_abs * umax + fabsf(bx.S) + bx.B * ge);
     }
     const bool fin = bs.usable && bx.usable && isfinite(est_hi) && isfinite(lb_hi) && isfinite(d_hi) && isfinite(g_add) && isfinite(g_err);
     return fin ? fmaxf(d_hi, lb_hi) : INFINITY;

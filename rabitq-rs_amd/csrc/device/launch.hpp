@@ -104,6 +104,7 @@ struct SelectParams {
     uint64_t filter_nbits;        // head evaluation — which counts filter-passing vectors only — can bound the k-th distance
     const uint64_t* ids;
     int head_exact;               // 0: Cauchy-Schwarz bound only (round 3)
+    SlackMul slack;               // TEST ONLY: multipliers of block_ub()'s rounding-slack terms (all 1 in the product)
     uint32_t* audit_dead;         // null, or (option lazy_audit) [nq][kAuditCap + 1] u32: the number of lists this query's selection dropped as
                                   // a whole, then their ids — exported WITHOUT changing any decision, with or without diagnostics or a
                                   // filter, so that a test can ask the oracle what the reference did with exactly those lists

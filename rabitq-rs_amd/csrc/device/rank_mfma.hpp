@@ -1203,7 +1203,7 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
                 head_info(r, g_add, g_err, gb, nvec);
                 const BlockSummary bs = P.bsum[gb + b];
                 const BlockSummaryEx bx = P.bsumx[gb + b];
-                myU = block_ub(bs, bx, g_add, g_err, qc, D, P.ex_bits) + 1e-4f * eps; // (+: |g_add| in the rounding slack is taken at the upper end)
+                myU = block_ub(bs, bx, g_add, g_err, qc, D, P.ex_bits, P.slack) + 1e-4f * eps; // (+: |g_add| in the rounding slack is taken at the upper end)
                 myN = (b + 1 == ((nvec + 31u) >> 5)) ? nvec - b * 32u : 32u;
             }
             float* candU = reinterpret_cast<float*>(part);

@@ -251,6 +251,8 @@ struct Replica {
     bool head_exact = true;  // lazy selection: a bound of the k-th distance from real estimates of the nearest list's first vectors
     bool lazy_filter = true; // search_filtered: lazy selection on the exact head evaluation's bound (filter-passing vectors only)
     bool lazy_fault_inject = false; // TEST ONLY: makes the lazy selection wrong on purpose (tests/test_gpu_round4.py: the audit must notice)
+    SlackMul slack;          // TEST ONLY (options slack_term / slack_milli): multipliers of block_ub()'s rounding-slack terms
+    int slack_term = 0;
     bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
@@ -1168,6 +1170,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     sp.force_fallback = ix->force_rank_fallback ? 1 : 0; sp.bsum = (const BlockSummary*)ix->bsum.p;
     sp.cnorm2 = (const float*)ix->cnorm2.p; sp.lsum = (const BlockSummary*)ix->lsum.p; sp.bsumx = (const BlockSummaryEx*)ix->bsumx.p;
     sp.dead_skipped = (uint32_t*)w->dead_skipped.p; sp.top_k = top_k; sp.ex_bits = ix->ex_bits;
+    sp.slack = ix->slack;
     sp.audit_dead = nullptr;
     if (ix->lazy_audit) { // diagnostic: the lists the selection drops as a whole are exported (rbq_debug_copy_workspace "audit_dead")
         if ((rc = w->audit_dead.ensure(nq * (size_t)(kAuditCap + 1) * 4))) return rc;
@@ -1916,6 +1919,12 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_trace")) ix->host_trace = value != 0;
         else if (!std::strcmp(name, "lazy_fault_inject")) ix->lazy_fault_inject = value != 0;
         else if (!std::strcmp(name, "lazy_audit")) ix->lazy_audit = value != 0;
+        else if (!std::strcmp(name, "slack_term")) ix->slack_term = value;
+        else if (!std::strcmp(name, "slack_milli")) { // TEST ONLY: term `slack_term` of block_ub()'s slack times value / 1000 (1000 = the product)
+            float* f[6] = {&ix->slack.ge, &ix->slack.eip, &ix->slack.est, &ix->slack.lb, &ix->slack.et, &ix->slack.dist};
+            if (ix->slack_term < 0 || ix->slack_term > 5) return fail(RBQ_INVALID_CONFIG, "slack_term is 0..5");
+            *f[ix->slack_term] = (float)value * 1e-3f;
+        }
         else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
         else if (!std::strcmp(name, "lazy_filter")) ix->lazy_filter = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;

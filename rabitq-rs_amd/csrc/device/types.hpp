@@ -42,6 +42,17 @@ struct BlockSummaryEx {
     float S, B, S1, B1, fadd_ex_abs, fres_ex_abs;
     uint32_t usable, pad;
 };
+// TEST ONLY: multipliers of the rounding-slack terms of block_ub() (kernels.hpp), all 1 in the product.  A test scales one term at a
+// time (debug options slack_term / slack_milli) and asks the lazy_audit check whether the selection still drops only lists the
+// reference skips: a term scaled far below zero must make the audit fire — the audit sees every term.
+struct SlackMul {
+    float ge = 1.0f;   // 0: |q - c| <= g_err (1 + 1e-4)
+    float eip = 1.0f;  // 1: E_ip, the u8 quantisation of the LUT + the sequential f32 sums
+    float est = 1.0f;  // 2: 1e-5 of the magnitudes of the 1-bit estimate's operations
+    float lb = 1.0f;   // 3: 1e-5 |f_error| g_err of the lower bound's last operation
+    float et = 1.0f;   // 4: 1e-3 (2^ex - 1) |q|_1, the f32 summation of the ex-code dot
+    float dist = 1.0f; // 5: 1e-5 of the magnitudes of the refined distance's operations
+};
 // One entry of a query's block stream (probe order, block order within a list).  `lbmin` is the block-level
 // lower bound of this (query, block) pair — everything in it but the running threshold is known when the
 // stream is written, so the scan's fill step is one 16-byte load and one compare per block.
