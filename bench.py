@@ -340,6 +340,29 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    # ---- pre-flight of an N-GPU run: every rank says which device it sits on, and rank 0 refuses to time
+    # anything unless the N ranks hold N DISTINCT devices and the RCCL group has N members.  The process simply exits (non-zero):
+    # nothing is re-executed, no GPU work has been queued yet.
+    preflight = None
+    if use_dist:
+        props = torch.cuda.get_device_properties(dev)
+        ident = f"{getattr(props, 'uuid', None) or ''}|pci={getattr(props, 'pci_bus_id', '?')}:{getattr(props, 'pci_device_id', '?')}|ordinal={local}"
+        print(f"[bench preflight] rank {rank}/{world}: device ordinal {local}, {props.name}, {ident}", file=sys.stderr, flush=True)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident if not os.environ.get("RBQ_BENCH_REHEARSAL") else f"{ident}|rank={rank}")
+        distinct = len(set(idents))
+        backend = dist.get_backend()
+        preflight = {"ranks": world, "distinct_devices": distinct, "backend": backend, "group_size": dist.get_world_size(),
+                     "rehearsal_on_one_gpu": bool(os.environ.get("RBQ_BENCH_REHEARSAL"))}
+        ok = dist.get_world_size() == world and (distinct == world or world == 1)
+        if not os.environ.get("RBQ_BENCH_REHEARSAL") and world > 1:
+            ok = ok and backend == "nccl"
+        if not ok:
+            if rank == 0:
+                print(f"[bench preflight] FAILED: {preflight} (identities: {idents})", file=sys.stderr, flush=True)
+            dist.destroy_process_group()
+            raise SystemExit(3)
+
     lib_devs = None
     if a.in_library:
         lib_devs = [0] * a.gpus if os.environ.get("RBQ_BENCH_REHEARSAL") else list(range(a.gpus))
@@ -756,6 +779,11 @@ def main():
                f"recall_at_{a.top_k}": recall, "recall_ok": recall >= 0.95,
                "ids_identical_to_one_replica_device_entry": same,
                "replicas": int(idx.device_count()), "rank_fallbacks": int(idx.rank_fallbacks()), "heap_restarts": int(idx.heap_restarts()),
+               # how replica 0's arrays reached the other replicas: hipMemcpyPeer, or the page-locked bounce buffer when the runtime
+               # refuses peer access (rbq_debug_bounce_copies counts the latter); and what the runtime says about peer access
+               "replica_copy": "bounce" if int(rq.index.lib().rbq_debug_bounce_copies()) > 0 else ("peer" if a.gpus > 1 else "none"),
+               "peer_access": [[bool(i == j or (lib_devs[i] != lib_devs[j] and torch.cuda.can_device_access_peer(lib_devs[i], lib_devs[j])))
+                                for j in range(a.gpus)] for i in range(a.gpus)] if a.gpus > 1 else None,
                "latency": None if a.no_latency else latency_leg(),
                "roofline": None, "cpu_baseline": None}
         free_sets(pin)
@@ -1143,6 +1171,7 @@ def main():
         "region_ms": [round(v * 1e3, 3) for v in dts],
         "per_rank_queries_per_s": per_rank,  # every rank's own median region (no max over ranks)
         "rccl_world_size": rccl_world,       # dist.get_world_size() of the nccl (= RCCL) group; null without one
+        "preflight": preflight,              # N > 1: distinct devices == ranks was checked before anything was timed
         "host_issue_ms_per_step": prof["issue_s"] / a.steps * 1e3,  # host time to enqueue one step (launches + gather), rank 0
         "higher_is_better": True,
         "scaling": "weak",

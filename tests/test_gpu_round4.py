@@ -399,7 +399,7 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_protocol():
     import subprocess
     import sys
     from test_gpu_round3 import _run_bench
-    args = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-extras", "--no-cpu", "--nbatches", "4", "--min-seconds", "0", "--no-latency",
+    args = ["--gpus", "1", "--steps", "48", "--warmup", "4", "--no-extras", "--no-cpu", "--nbatches", "4", "--min-seconds", "0.2", "--no-latency",
             "--n", "200000", "--nlist", "1024", "--nprobe", "32"]
     plain = _run_bench(args, {})
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -414,12 +414,12 @@ def test_bench_under_torchrun_with_one_rank_is_the_plain_protocol():
                           "--master-port", str(port), os.path.join(root, "bench.py")], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     tr = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "higher_is_better", "timed_regions", "rccl_world_size"):
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "higher_is_better", "rccl_world_size"):
         assert tr[k] == plain[k], (k, tr[k], plain[k])
     assert tr["config"] == plain["config"] and tr["rccl_world_size"] is None and len(tr["per_rank_queries_per_s"]) == 1
-    assert tr["pruned"]["launches"] == plain["pruned"]["launches"] == 6
     assert abs(tr["recall_at_10"] - plain["recall_at_10"]) < 1e-3          # (the harness k-means sums with atomics: two builds differ in a few list assignments)
-    assert 0.2 < tr["value"] / plain["value"] < 5.0                          # (two six-step runs: the rate itself is noisy)
+    # two runs of >= 48-step regions (median region each): SCALE's N = 1 point must agree with BENCH within the run-to-run noise
+    assert 0.75 < tr["ms_per_step"] / plain["ms_per_step"] < 1.25, (tr["ms_per_step"], plain["ms_per_step"])
 
 
 def test_staging_helpers_under_concurrent_callers_and_replicas():
