@@ -120,6 +120,9 @@ def parse():
                          "batch_search binding, src/ivf.rs:1743-1752) instead of one process per GPU")
     ap.add_argument("--caller-threads", type=int, default=1, help="--in-library: host threads calling rbq_search_batch concurrently")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency leg")
+    ap.add_argument("--no-wave-roofline", action="store_true",
+                    help="skip the roofline leg's second half (the bound-off configuration through k_scanw): counter passes of "
+                         "tools/profile_round.sh, whose per-kernel medians should not be dominated by eager-selection launches")
     argv = json.loads(os.environ["RBQ_BENCH_ARGV"]) if (os.environ.get("RBQ_BENCH_ARGV") and len(sys.argv) == 1) else sys.argv[1:]
     a = ap.parse_args(argv)
     if a.config:
@@ -825,6 +828,8 @@ def main():
         # size; the library picks k_scan when every block is streamed)
         wave = None
         try:
+            if a.no_wave_roofline:
+                raise RuntimeError("skipped (--no-wave-roofline)")
             idx.set_option("scan_wave", 1)
             _, _, p3 = run_timed(idx, q_all, a.nprobe, n_rf, 2, 1, gather=False)
             ids_w = search_ids(idx, q_all[:2], a.nprobe)

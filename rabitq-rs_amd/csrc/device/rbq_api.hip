@@ -117,6 +117,7 @@ struct Workspace {
     DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window, audit_dead;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
+    bool latency_first = false; // this launch chain belongs to a host call that waits for it (rbq_search_batch below kHostWaveMinQueries)
     void release() {
         for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
                           &heap_ws, &key_window, &audit_dead})
@@ -224,6 +225,8 @@ inline int scan_wave_default() {
 // scan_wave = 2: batches of at least this many queries go to k_scanw (a query costs one resident wave instead of four: the
 // pipelined rate), smaller ones to k_scan (four waves shorten ONE query's chain: the latency of a small call)
 constexpr uint64_t kScanWaveMinQueries = 128;
+// ... and rbq_search_batch (host buffers; the caller waits for the call) from this many queries per call
+constexpr uint64_t kHostWaveMinQueries = 4096;
 
 // One device-resident copy of the index.
 struct Replica {
@@ -1099,7 +1102,10 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     // scan_wave = 2 (default): the wave-per-query kernel serves the pruned regime of batches large enough to fill the chip with
     // waves; with the block bound off (every probed block streamed: the roofline configuration) the four-wave kernel streams
     // at twice its rate and serves the call.  Results are identical either way.
-    P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries && !ix->no_block_bound)) ? 1u : 0u;
+    // A host call (rbq_search_batch) that waits for ONE chain of kernels is served by the kernel with the shorter chain (k_scan's
+    // four waves finish a 1024-query launch in 0.10 ms, k_scanw's single wave in 0.14 ms) until the call is large enough for the rate
+    // to matter more than the last chain's latency.
+    P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries && !ix->no_block_bound && !w->latency_first)) ? 1u : 0u;
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
         int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);
@@ -1399,7 +1405,9 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             k_ids = (uint64_t*)(dp + op.o_ids); k_scores = (float*)(dp + op.o_scores); k_counts = (uint32_t*)(dp + op.o_counts);
             k_diag = diag ? (rbq_diag*)(dp + op.o_diag) : nullptr;
         }
+        w->latency_first = nq < kHostWaveMinQueries;
         rc = search_device(ix, w, d_q, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag, w->stream);
+        w->latency_first = false;
         if (rc) return rc;
         if (ix->rerank) {
             if ((rc = w->h_out.ensure(op.total))) return rc;

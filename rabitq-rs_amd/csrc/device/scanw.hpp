@@ -38,6 +38,9 @@ namespace rbq {
 #ifndef RBQ_W_RANKRUN1
 #define RBQ_W_RANKRUN1 0        // 1: RankRun (a data-parallel merge of a whole batch) also below top_k 64 (measured: no gain over the sorted run)
 #endif
+#ifndef RBQ_W_PAIRS_RANK
+#define RBQ_W_PAIRS_RANK 1     // ... for the RankRun instantiations (top_k >= 64: five times the refinements of top_k = 10, half the rounds)
+#endif
 #ifndef RBQ_W_PAIRS
 #define RBQ_W_PAIRS 0          // a refine round requests two candidates per 16-lane group (finished as two halves of four)
 #endif
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(64, (TR == 1 ? RBQ_SCANW_WAVES1 : RBQ_SCANW_WAVES))
     };
 
     constexpr uint32_t kNU = ex_w4((uint32_t)(DT ? DT : 16), (uint32_t)(EX ? EX : 2)); // code units per lane and vector
-    constexpr bool kDual = RBQ_W_PAIRS && DT != 0 && EX != 0 && kNU <= 3u; // two candidates per 16-lane group (packed FMAs: one query read for both)
+    constexpr bool kDual = (RBQ_W_PAIRS || (RBQ_W_PAIRS_RANK && TR > 1)) && DT != 0 && EX != 0 && kNU <= 3u; // two candidates per 16-lane group (packed FMAs: one query read for both)
     constexpr uint32_t G = kDual ? 8u : 4u; // candidates refined per round
     // the ex-code units of a round are requested into registers and decoded later (compile-time dimensions up to 4 units per
     // lane: D <= 1344 at 6 bits); otherwise they are loaded where they are decoded

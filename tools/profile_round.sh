@@ -15,10 +15,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_on -
 echo "[profile] FETCH_SIZE (bound on) done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_off -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --option block_bound=0 "$@" > $out/bench_fetch_off.json 2> $out/fetch_off.log || exit 1
 echo "[profile] FETCH_SIZE (bound off) done"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --streams 1 "$@" > $out/bench_sq.json 2> $out/sq.log || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --streams 1 --no-wave-roofline "$@" > $out/bench_sq.json 2> $out/sq.log || exit 1
 echo "[profile] SQ pass done"
 # where the resident waves' cycles go: parked (s_waitcnt / barrier), issue-stalled, issuing; LDS-issue stalls (8 SQ counters per pass)
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $out/sqwait -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --streams 1 "$@" > $out/bench_sqwait.json 2> $out/sqwait.log || echo "[profile] wait-counter pass FAILED (see $out/sqwait.log)"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $out/sqwait -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --min-seconds 0 --nbatches 8 --streams 1 --no-wave-roofline "$@" > $out/bench_sqwait.json 2> $out/sqwait.log || echo "[profile] wait-counter pass FAILED (see $out/sqwait.log)"
 echo "[profile] SQ wait pass done"
 python3 tools/profile_summary.py $out "$@" > $out/summary.md
 cat $out/summary.md

@@ -89,6 +89,18 @@ for sub, lab in (("fetch_on", "on"), ("fetch_off", "off")):
             v = c["FETCH_SIZE"]
             med = statistics.median(v)
             print(f"| `{k}` | {lab} | {len(v)} | {med / 1e3:.1f} | {2 * med / 1e3:.1f} |")
+# the bound-off HBM bytes per launch of the four-wave scan kernel, for bench.py's roofline.traffic (profiles/rN/pmc_traffic.json)
+try:
+    off = pmc("fetch_off")
+    cand = [(k, c["FETCH_SIZE"]) for k, c in off.items() if "k_scan<" in k and "FETCH_SIZE" in c]
+    if cand:
+        k, v = max(cand, key=lambda kv: statistics.median(kv[1]))
+        with open(f"{d}/pmc_traffic.json", "w") as f:
+            json.dump({"bytes": 2.0 * statistics.median(v) * 1e3, "kernel": k, "launches": len(v),
+                       "source": "rocprofv3 --pmc FETCH_SIZE (its own pass), x2 on gfx950 (MI355X_MICROARCH.md), median over the bound-off launches: "
+                                 "profiles/r5/summary_headline.md"}, f)
+except Exception as e:  # noqa: BLE001
+    print(f"(pmc_traffic.json not written: {e})")
 for sub in ("fetch_on", "fetch_off"):
     bb = bench_line(f"{d}/bench_{sub}.json")
     if bb:
