@@ -68,6 +68,12 @@ hipError_t launch_rank_f32(const RankParams& p, dim3 grid, hipStream_t s) {
 } // namespace
 
 hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s) {
+    if (p.split && p.wide) {
+        // very large problems (cfg5: 16 384 x 65 536): 128 x 256 tiles, each wave a 64 x 64 sub-tile — 8 LDS fragment reads per 12 MFMAs
+        // instead of 6 per 6, one workgroup (123 KB of LDS) per compute unit
+        dim3 grid((p.nlist + 255) / 256, (p.nq + 127) / 128);
+        return p.metric == 0 ? launch_rank_split<0, 2, 2, 2, 4>(p, grid, device, s) : launch_rank_split<1, 2, 2, 2, 4>(p, grid, device, s);
+    }
     const uint32_t T = p.big ? 128u : 64u;
     dim3 grid((p.nlist + T - 1) / T, (p.nq + T - 1) / T);
     if (p.split) {

@@ -60,6 +60,7 @@ struct RankParams {
     float* scores; // [nq][nlist]
     bool split;    // split-bf16 MFMA GEMM (else f32 MFMA)
     bool big;      // 128x128 tiles
+    bool wide;     // 128x256 tiles (split-bf16 only): problems of at least 2048 such tiles
 };
 hipError_t launch_rank_exact(const RankParams& p, hipStream_t s);
 hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s);

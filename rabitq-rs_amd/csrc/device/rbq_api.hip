@@ -258,6 +258,7 @@ struct Replica {
     int slack_term = 0;
     bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
+    int rank_tile = 0;         // option rank_tile: tile of the split-bf16 ranking GEMM (0 = by problem size)
     uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
                                // workspace of the stream as the last full call wrote it — results are then those of THAT batch (rate probes only)
     int scan_wave = scan_wave_default(); // which scan kernel serves a call: 0 = k_scan (one workgroup per query), 1 = k_scanw (one wave per
@@ -1167,6 +1168,10 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     rp.consts = (const QueryConsts*)w->consts.p; rp.cnorm2 = (const float*)ix->cnorm2.p; rp.nq = (uint32_t)nq; rp.nlist = nlist; rp.D = D;
     rp.scores = (float*)w->scores.p; rp.split = split_rank;
     rp.big = !ix->small_rank_tiles && (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
+    // option rank_tile: 0 = by problem size, 64 / 128 / 256 = forced (tests; A/B)
+    rp.wide = ix->rank_tile == 256 || (ix->rank_tile == 0 && !ix->small_rank_tiles && (uint64_t)((nlist + 255) / 256) * ((nq + 127) / 128) >= 2048);
+    if (ix->rank_tile == 64) rp.big = false;
+    if (ix->rank_tile == 128) rp.big = true;
     SelectParams sp;
     sp.scores = (float*)w->scores.p; sp.nq = (uint32_t)nq; sp.nlist = nlist; sp.nprobe = nprobe; sp.metric = ix->metric;
     sp.rot = (const float*)w->rot.p; sp.cent = (const float*)ix->centroids.p; sp.D = D; sp.consts = (const QueryConsts*)w->consts.p;
@@ -1915,6 +1920,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "exact_rank")) ix->exact_rank = value != 0;
         else if (!std::strcmp(name, "exact_heap")) ix->exact_heap = value != 0;
         else if (!std::strcmp(name, "lazy_select")) ix->lazy_select = value != 0;
+        else if (!std::strcmp(name, "rank_tile")) ix->rank_tile = value;
         else if (!std::strcmp(name, "stage_mask")) ix->stage_mask = (uint32_t)value & 0xfu;
         else if (!std::strcmp(name, "scan_wave")) ix->scan_wave = value < 0 ? scan_wave_default() : (value > 2 ? 2 : value);
         else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;

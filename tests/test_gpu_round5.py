@@ -370,3 +370,18 @@ def test_every_slack_term_of_block_ub_is_seen_by_the_audit(term, bits):
         assert viol == 0, (term, milli, viol)
         assert np.array_equal(ids, want)
     idx.close()
+
+
+def test_rank_gemm_tile_variants_select_the_same_probes():
+    """The split-bf16 ranking GEMM has three tile shapes (64 x 64, 128 x 128, and — round 5, for cfg5-sized problems — 128 x 256 with a
+    64 x 64 sub-tile per wave); the shape changes the accumulation grouping of nothing (each score is one K-ordered chain), so ids,
+    scores and diagnostics must equal the oracle's with every shape forced, L2 and inner product, ragged edges included."""
+    for metric, nlist, dim in ((0, 300, 192), (1, 260, 128)):
+        data, built = build_index(n=12000, dim=dim, nlist=nlist, total_bits=7, metric=metric, normalize=(metric == 1), seed=1001 + metric)
+        idx = rq.IvfRabitqIndex.from_built(built)
+        q = make_dataset(150, dim, 40, 1002, normalize=(metric == 1))
+        for tile in (64, 128, 256, 0):
+            idx.set_option("rank_tile", tile)
+            _compare(built, idx, q, 10, 40)
+            assert idx.rank_fallbacks() == 0
+        idx.close()
