@@ -258,6 +258,7 @@ struct Replica {
     int slack_term = 0;
     bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
+    int host_wave_policy = 0;  // option host_wave_policy (see search_host)
     int rank_tile = 0;         // option rank_tile: tile of the split-bf16 ranking GEMM (0 = by problem size)
     uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
                                // workspace of the stream as the last full call wrote it — results are then those of THAT batch (rate probes only)
@@ -1410,7 +1411,9 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
             k_ids = (uint64_t*)(dp + op.o_ids); k_scores = (float*)(dp + op.o_scores); k_counts = (uint32_t*)(dp + op.o_counts);
             k_diag = diag ? (rbq_diag*)(dp + op.o_diag) : nullptr;
         }
-        w->latency_first = nq < kHostWaveMinQueries;
+        // which sub-batches of a call below kHostWaveMinQueries take the short-chain kernel: all (policy 0), only the LAST one — the chain
+        // the caller actually waits for; the earlier ones overlap it — (1), none (2)
+        w->latency_first = nq < kHostWaveMinQueries && (ix->host_wave_policy == 0 || (ix->host_wave_policy == 1 && j + 1 == nsub));
         rc = search_device(ix, w, d_q, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag, w->stream);
         w->latency_first = false;
         if (rc) return rc;
@@ -1921,6 +1924,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "exact_heap")) ix->exact_heap = value != 0;
         else if (!std::strcmp(name, "lazy_select")) ix->lazy_select = value != 0;
         else if (!std::strcmp(name, "rank_tile")) ix->rank_tile = value;
+        else if (!std::strcmp(name, "host_wave_policy")) ix->host_wave_policy = value;
         else if (!std::strcmp(name, "stage_mask")) ix->stage_mask = (uint32_t)value & 0xfu;
         else if (!std::strcmp(name, "scan_wave")) ix->scan_wave = value < 0 ? scan_wave_default() : (value > 2 ? 2 : value);
         else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;
