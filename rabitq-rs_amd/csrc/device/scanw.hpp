@@ -14,13 +14,16 @@
 //   fill   one stream entry per lane: block-level lower bound vs the threshold -> live-block queue (wave-private LDS)
 //   tile   two live blocks, lane = vector (half-wave = block): sign codes -> LDS LUT lookups -> fused epilogue;
 //          the candidates stay IN REGISTERS (lane j = candidate j, already in stream order), no compaction
-//   rounds lazy refine: the next (up to 8) candidates whose lower bound is below the current TRUE threshold, 16 lanes per
-//          candidate (two candidates per group on one query read), then the reference's exact sequential
-//          prune / push / pop loop over them in scalar registers
-// No barrier, no hand-over, the threshold is never stale inside a tile's replay; the next tile's block records are
-// requested before the refine rounds of the current one.  A query costs one wave for about the time k_scan keeps four.
-// Exactness is k_scan's: the tile prunes with the threshold of its start (T only shrinks: `lb >= T_then` implies the
-// reference skipped the candidate too), everything else is replayed in stream order against the running threshold.
+//   rounds lazy refine: the next (up to 4; from top_k 64: 8, finished as two halves) candidates whose lower bound is below the
+//          current TRUE threshold, 16 lanes per candidate, every code unit of the round requested before the first is decoded;
+//          then the reference's exact sequential prune / push / pop loop over them in scalar registers (top_k < 64) or one
+//          RankRun merge per half (scan.hpp)
+// No barrier, no hand-over, the threshold is never stale inside a tile's replay.  Vector-memory results come back in issue
+// order, so the order of the requests is the order of use: a round's code units first, then (once per tile) the next tile's
+// block records, which arrive while the round is decoded and replayed.  A query costs one wave for about 1.6 x the time k_scan
+// keeps four.  Exactness is k_scan's: the tile prunes with the threshold of its start (T only shrinks: `lb >= T_then` implies
+// the reference skipped the candidate too), everything else is replayed in stream order against the running threshold.
+// Equal distances: the LAZY-TIE rule (below, at `amb_min`).
 #pragma once
 #include "scan.hpp"
 
@@ -98,7 +101,8 @@ __device__ __forceinline__ float lane_shfl_f32(float v, uint32_t src_lane) {
 }
 
 // EX: compile-time ex_bits (0/2/6) when DT != 0; ignored (runtime P.ex_bits) when DT == 0.  TR: registers per lane of the
-// top-k (1: top_k <= 63; 2: <= 128; 4: <= 255).  Not served here (k_scan does): MSTG scans, heaps outside the registers.
+// top-k (1: top_k <= 63; 2: <= 127; 4: <= 255).  Not served here (k_scan does): MSTG scans, heaps outside the registers, and
+// instantiations whose code object reports spilled registers (k_scanw.hip).
 template <int DT, int EX, int TR>
 __global__ __launch_bounds__(64, (TR == 1 ? RBQ_SCANW_WAVES1 : RBQ_SCANW_WAVES)) void k_scanw(ScanParams P) {
     extern __shared__ __align__(16) unsigned char smraw[];
