@@ -8,6 +8,7 @@
 #include "launch.hpp"
 #include "query_kernels.hpp"
 #include "rank_mfma.hpp"
+#include "latency.hpp"
 
 namespace rbq {
 
@@ -34,6 +35,23 @@ hipError_t launch_prep(const PrepParams& p, int device, hipStream_t s) {
         hipLaunchKernelGGL(k_prep_wave, dim3((p.nq + qpw - 1) / qpw), dim3(kThreads), lds, s, p.queries, p.nq, p.dim, p.D, p.Dc,
                            p.rotator, p.rot_blob, p.trunc, p.fac, p.ex_bits, p.rot, p.lut, p.consts, p.rot_hi, p.rot_lo);
     }
+    return hipGetLastError();
+}
+
+// latency-first front of a small call (latency.hpp): rotation + constants + LUT + the exact canonical score of every list, one launch
+hipError_t launch_lat_front(const PrepParams& p, const RankParams& r, int device, hipStream_t s) {
+    static LdsAttrCache attr;
+    LatFrontParams P;
+    P.queries = p.queries; P.nq = p.nq; P.dim = p.dim; P.D = p.D; P.Dc = p.Dc; P.rotator = p.rotator; P.rot_blob = p.rot_blob;
+    P.trunc = p.trunc; P.fac = p.fac; P.ex_bits = p.ex_bits; P.rot = p.rot; P.lut = p.lut; P.consts = p.consts;
+    P.cent = r.cent; P.nlist = r.nlist; P.metric = r.metric; P.scores = r.scores;
+    P.rot_hi = p.rot_hi; P.rot_lo = p.rot_lo; P.scorers = r.scores ? 1u : 0u;
+    const dim3 grid(P.scorers ? (r.nlist + kLatLists - 1) / kLatLists + 1 : 1u, p.nq);
+    const size_t lds = (size_t)p.D * 4 * 2 + p.D / 2;
+    if (probe_stage(0, reinterpret_cast<const void*>(&k_lat_front), grid, kThreads, lds)) return hipSuccess;
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_lat_front), lds, device);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lat_front, grid, dim3(kThreads), lds, s, P);
     return hipGetLastError();
 }
 

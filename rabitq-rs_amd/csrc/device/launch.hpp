@@ -64,6 +64,8 @@ struct RankParams {
 };
 hipError_t launch_rank_exact(const RankParams& p, hipStream_t s);
 hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s);
+// latency-first front of a small call (latency.hpp): prep + the exact canonical score of every list in ONE launch (FhtKac / no rotator)
+hipError_t launch_lat_front(const PrepParams& p, const RankParams& r, int device, hipStream_t s);
 
 constexpr uint32_t kAuditCap = 1023; // dead lists exported per query under lazy_audit (a shortlist holds fewer)
 struct SelectParams {

@@ -227,6 +227,12 @@ inline int scan_wave_default() {
 constexpr uint64_t kScanWaveMinQueries = 128;
 // ... and rbq_search_batch (host buffers; the caller waits for the call) from this many queries per call
 constexpr uint64_t kHostWaveMinQueries = 4096;
+// Latency-first front (latency.hpp): one launch rotates the query, builds its LUT and scores EVERY list exactly, spread over
+// n_lists / 32 workgroups per query.  It re-reads the centroid table once per query, so it serves calls of a few queries only
+// (every query's pass over the table must stay a few microseconds: n_lists x D x 4 bytes x nq within kLatMaxBytes).
+constexpr uint64_t kLatMaxQueries = 8;
+constexpr uint64_t kLatMaxBytes = 96ull << 20;
+constexpr uint64_t kPrepWgMaxQueries = 512; // up to here the preparation runs one WORKGROUP per query (latency.hpp without the scorers)
 
 // One device-resident copy of the index.
 struct Replica {
@@ -259,6 +265,7 @@ struct Replica {
     bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     int host_wave_policy = 0;  // option host_wave_policy (see search_host)
+    int latency_path = 1;      // option latency_path: small calls (see kLatMaxQueries) take the latency-first front (latency.hpp); 0 = never
     int rank_tile = 0;         // option rank_tile: tile of the split-bf16 ranking GEMM (0 = by problem size)
     uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
                                // workspace of the stream as the last full call wrote it — results are then those of THAT batch (rate probes only)
@@ -1153,7 +1160,21 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     }
     unsigned long long* prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     const uint32_t smask = ix->stage_mask;
-    if (smask & 1u) {
+    // small calls: prep + exact scores of every list in one launch (the ranking GEMM and its launch boundary are skipped)
+    const bool lat_front = ix->latency_path && nq <= kLatMaxQueries && ix->rotator != 0 && !ix->wg_prep && !ix->exact_rank && !big_nprobe &&
+                           !ix->f32_rank && (uint64_t)nlist * D * 4 * nq <= kLatMaxBytes && D % 16 == 0 && smask == 0xfu;
+    if (lat_front) {
+        ProfScope ps(ix, 0, stream);
+        PrepParams p;
+        p.queries = d_queries; p.nq = (uint32_t)nq; p.dim = ix->dim; p.D = D; p.Dc = Dc; p.rotator = (int)ix->rotator;
+        p.rot_blob = (const uint8_t*)ix->rot_blob.p; p.trunc = ix->trunc; p.fac = ix->fac; p.ex_bits = ix->ex_bits;
+        p.rot = (float*)w->rot.p; p.lut = (uint8_t*)w->lut.p; p.consts = (QueryConsts*)w->consts.p;
+        p.rot_hi = nullptr; p.rot_lo = nullptr; p.wg_prep = false;
+        RankParams r;
+        r.metric = ix->metric; r.cent = (const float*)ix->centroids.p; r.nlist = nlist; r.D = D; r.nq = (uint32_t)nq;
+        r.scores = (float*)w->scores.p;
+        HIP_TRY(launch_lat_front(p, r, ix->device, stream));
+    } else if (smask & 1u) {
         ProfScope ps(ix, 0, stream);
         PrepParams p;
         p.queries = d_queries; p.nq = (uint32_t)nq; p.dim = ix->dim; p.D = D; p.Dc = Dc; p.rotator = (int)ix->rotator;
@@ -1161,7 +1182,15 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         p.rot = (float*)w->rot.p; p.lut = (uint8_t*)w->lut.p; p.consts = (QueryConsts*)w->consts.p;
         p.rot_hi = split_rank ? (uint16_t*)w->rot_hi.p : nullptr; p.rot_lo = split_rank ? (uint16_t*)w->rot_lo.p : nullptr;
         p.wg_prep = ix->wg_prep;
-        HIP_TRY(launch_prep(p, ix->device, stream));
+        // batches a caller waits for (a few hundred queries: the chip is not full): a workgroup per query — the serial sums on one
+        // wave while the others build the LUT (latency.hpp, preparation only); full batches keep one wave per query (k_prep_wave)
+        if (ix->latency_path && nq <= kPrepWgMaxQueries && ix->rotator != 0 && !ix->wg_prep && D % 16 == 0) {
+            RankParams r;
+            r.metric = ix->metric; r.cent = nullptr; r.nlist = 0; r.D = D; r.nq = (uint32_t)nq; r.scores = nullptr;
+            HIP_TRY(launch_lat_front(p, r, ix->device, stream));
+        } else {
+            HIP_TRY(launch_prep(p, ix->device, stream));
+        }
     }
     RankParams rp;
     rp.metric = ix->metric; rp.rot = (const float*)w->rot.p; rp.rot_hi = (const uint16_t*)w->rot_hi.p; rp.rot_lo = (const uint16_t*)w->rot_lo.p;
@@ -1211,7 +1240,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         if (smask & 2u) { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_exact(rp, stream)); }
         if (smask & 4u) { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_exact(sp, ix->device, stream, kw)); }
     } else {
-        if (smask & 2u) { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); }           // approximate scores: one MFMA GEMM
+        if ((smask & 2u) && !lat_front) { ProfScope ps(ix, 1, stream); HIP_TRY(launch_rank_gemm(rp, ix->device, stream)); } // approximate scores: one MFMA GEMM
         if (smask & 4u) { ProfScope ps(ix, 2, stream); HIP_TRY(launch_select_mfma(sp, ix->device, stream)); }         // shortlist + exact canonical scores + exact select
     }
     if ((smask & 8u) && (rc = scan_stage(ix, w, nq, nprobe, top_k, wl_stride, d_filter, filter_nbits, d_ids, d_scores, d_counts, d_diag,
@@ -1925,6 +1954,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "lazy_select")) ix->lazy_select = value != 0;
         else if (!std::strcmp(name, "rank_tile")) ix->rank_tile = value;
         else if (!std::strcmp(name, "host_wave_policy")) ix->host_wave_policy = value;
+        else if (!std::strcmp(name, "latency_path")) ix->latency_path = value;
         else if (!std::strcmp(name, "stage_mask")) ix->stage_mask = (uint32_t)value & 0xfu;
         else if (!std::strcmp(name, "scan_wave")) ix->scan_wave = value < 0 ? scan_wave_default() : (value > 2 ? 2 : value);
         else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;
@@ -1993,9 +2023,13 @@ int rbq_debug_stage_resources(rbq_index* h, uint64_t nq, uint32_t top_k, uint32_
     for (int st = 0; st < 4; ++st) {
         const KernelProbe& k = probes.k[st];
         hipFuncAttributes fa;
-        if (!k.fn) return fail(RBQ_DEVICE, "stage was not probed");
-        HIP_TRY(hipFuncGetAttributes(&fa, k.fn));
         uint32_t* o = out + 6 * st;
+        if (!k.fn) { // a stage this call shape does not launch (the latency-first front of a small call covers prep AND rank): zeros
+            if (st != 1) return fail(RBQ_DEVICE, "stage was not probed");
+            for (int j = 0; j < 6; ++j) o[j] = 0;
+            continue;
+        }
+        HIP_TRY(hipFuncGetAttributes(&fa, k.fn));
         o[0] = k.grid_x * (k.grid_y ? k.grid_y : 1u); o[1] = k.block; o[2] = (uint32_t)fa.numRegs;
         o[3] = (uint32_t)(fa.sharedSizeBytes + k.dyn_lds); o[4] = (uint32_t)fa.localSizeBytes; o[5] = 0;
     }

@@ -781,6 +781,9 @@ struct SortedRun {
 #ifndef RBQ_REPLAY_PRIO
 #define RBQ_REPLAY_PRIO 3
 #endif
+#ifndef RBQ_SCAN_LAZY_TIES
+#define RBQ_SCAN_LAZY_TIES 1  // k_scan settles equal distances by the lazy-tie rule (0: any equal pair re-runs the query, rounds 2-4)
+#endif
 #ifndef RBQ_HEAVY_PER
 #define RBQ_HEAVY_PER 1
 #endif
@@ -1004,6 +1007,11 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
     if (kRank && fast) RankRun<TR>::clear(rh); // keys, empty lanes marked
     int bag_dk = 0x7f800000; // RankRun: bits of the k-th distance (valid once the run holds top_k entries)
     bool tie_pending = false; // replay wave: a distance tie was met, the query will be re-run with the exact heap
+    // LAZY TIES (round 5, as in k_scanw — the rule and its proof are at `amb_min` in scanw.hpp): equal distances do not end the fast
+    // pass; the smallest key with which an element left (or was turned away) while its twin stayed is recorded, and the final run
+    // decides at the end of the stream whether the reference's result depends on the layout of its heap.
+    constexpr bool kLazyTies = RBQ_SCAN_LAZY_TIES != 0;
+    int amb_min = 0x7fffffff;
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
@@ -1331,9 +1339,8 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
 #else
                     const bool serial_counts = count_skips;
 #endif
-                    int amb_unused = 0;
                     const bool tie = RankRun<TR>::merge_batch(rh, top_k, bt.mt, bt.v_lb, v_d, v_s, lane, serial_counts,
-                                                              reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk, false, amb_unused
+                                                              reinterpret_cast<int*>(heap_d), heap_s, c_skip, c_ext, c_est, dk, kLazyTies, amb_min
 #if RBQ_STAMPS == 4
                                                               , mst
 #endif
@@ -1372,15 +1379,21 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
                         if ((dbits & 0x7f800000) == 0x7f800000) continue;          // non-finite distance: dropped
                         ++c_est;
                         const int ke = HeapOps::key(dbits);
-                        if (len_s == top_k) {
-                            const int kk = HeapOps::key(dk);
+                        const bool was_full = len_s == top_k;
+                        const int kk = HeapOps::key(dk);
+                        if (was_full) {
                             if (ke > kk) continue;                                  // pushed and popped again: no change
-                            if (ke == kk) { tie = true; continue; }                 // which of the equal maxima leaves depends on the heap layout
+                            if (ke == kk) { // turned away with the maximum's key: which of the equal maxima leaves depends on the heap layout
+                                if (kLazyTies) amb_min = amb_min < kk ? amb_min : kk; else tie = true;
+                                continue;
+                            }
                         }
                         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)v_s, (int)j);
-                        tie |= SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane);
+                        const bool eqk = SortedRun<TR>::insert(rh.hd, rh.hs, rh.xd, rh.xs, len_s, dbits, slot, lane); // (lazy: equal keys side by side)
+                        if (!kLazyTies) tie |= eqk;
                         len_s = len_s < top_k ? len_s + 1u : len_s; // a full run drops its (new) entry top_k
                         dk = SortedRun<TR>::kth(rh.hd, rh.xd, len_s, top_k);
+                        if (kLazyTies && was_full && HeapOps::key(dk) == kk) amb_min = amb_min < kk ? amb_min : kk; // the old maximum left, its twin stays
                     }
                     rh.len = len_s;
                     n_skip += c_skip; n_ext += c_ext; n_est += c_est;
@@ -1486,7 +1499,27 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
         qcount -= n;
         ++tile;
     }
-    if (tie_pending && lane == 0) s_restart = 1u; // (a tie met in the last tile)
+    if (kLazyTies && !scanner && fast && !tie_pending) { // the final look of the lazy-tie rule (k_scanw's, same registers)
+        const uint32_t lenf = HeapOps::uni(rh.len);
+        bool eq = false;
+        int maxkey = (int)0x80000000;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const uint32_t i = (uint32_t)r * 64u + lane;
+            const int b = r == 0 ? rh.hd : rh.xd[r];
+            const int kv = kRank ? b : HeapOps::key(b);
+            int below = __builtin_amdgcn_update_dpp((int)0x80000000, kv, 0x138, 0xf, 0xf, false); // wave_shr:1
+            if (r > 0) {
+                const int pb = r == 1 ? rh.hd : rh.xd[r - 1];
+                const int carry = __builtin_amdgcn_readlane(kRank ? pb : HeapOps::key(pb), 63);
+                below = lane == 0 ? carry : below;
+            }
+            eq |= i >= 1u && i < lenf && kv == below;
+            if (lenf && (lenf - 1u) >> 6 == (uint32_t)r) maxkey = __builtin_amdgcn_readlane(kv, (int)((lenf - 1u) & 63u));
+        }
+        tie_pending = __ballot(eq) != 0ull || (lenf == top_k && maxkey == amb_min);
+    }
+    if (tie_pending && lane == 0) s_restart = 1u; // (a tie met in the last tile; lazy ties: decided by the final run)
     lds_barrier(); // F: the replay wave has consumed the last tile
     if (!s_restart) break;
     __syncthreads(); // every wave has seen the flag
@@ -1501,6 +1534,7 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
     rh.len = 0;
     bag_dk = 0x7f800000;
     tie_pending = false;
+    amb_min = 0x7fffffff;
     __syncthreads();
   }
     if (!scanner) {

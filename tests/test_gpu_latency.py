@@ -1,0 +1,137 @@
+"""GPU parity tests of the latency-first path of SMALL calls (round 5; csrc/device/latency.hpp): one launch rotates the query,
+builds its constants and LUT and scores every list in the reference's summation order (src/rotation.rs:350-401, src/ivf.rs:798-878,
+:1782-1835, src/math.rs:154-245).  Bar: the stage outputs equal the oracle's bit for bit, the results equal the oracle's AND the
+batch path's (option latency_path = 0) bit for bit, at nq in {1, 3, 8} incl. degenerate queries."""
+import numpy as np
+import pytest
+
+import oracle
+import rabitq_rs_amd as rq
+from conftest import build_index, make_dataset
+from test_gpu_parity import _compare
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, dim, nlist, bits, metric, rotator, top_k, nprobe, uniform
+    pytest.param(10000, 128, 256, 7, 0, 1, 10, 32, True, id="cfg1_10k_d128_7bit_L2"),
+    pytest.param(6000, 960, 48, 7, 0, 1, 10, 12, False, id="gist_shape_d960_7bit_L2"),
+    pytest.param(6000, 960, 48, 3, 1, 1, 10, 16, False, id="gist_shape_d960_3bit_IP"),
+    pytest.param(5000, 768, 40, 7, 0, 1, 10, 10, False, id="d768_7bit_L2"),
+    pytest.param(4000, 128, 33, 1, 1, 1, 10, 8, False, id="d128_1bit_IP_33_lists"),
+    pytest.param(4000, 100, 32, 7, 0, 1, 10, 8, False, id="d100_pad128_kac_7bit_L2"),
+    pytest.param(3000, 200, 24, 3, 0, 1, 5, 24, False, id="d200_pad256_3bit_all_lists"),
+    pytest.param(3000, 64, 24, 7, 1, 0, 10, 6, False, id="matrix_rotator_d64_7bit_IP_batch_path_serves_it"),
+    pytest.param(5000, 320, 40, 7, 0, 1, 100, 20, False, id="d320_top100"),
+    pytest.param(1500, 24, 12, 7, 1, 1, 10, 5, False, id="kac_d24_trunc16_7bit_IP"),
+    pytest.param(9000, 128, 1000, 7, 0, 1, 10, 64, False, id="d128_1000_lists"),
+]
+
+
+def _front_taken(idx, nq, top_k, nprobe):
+    r = idx.stage_resources(nq, top_k, nprobe)
+    return r["rank"]["workgroups"] == 0 and r["prep"]["workgroups"] > 0
+
+
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,rot,top_k,nprobe,uniform", CASES)
+def test_latency_path_matches_oracle_and_batch_path(n, dim, nlist, bits, metric, rot, top_k, nprobe, uniform):
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=rot, uniform=uniform,
+                              normalize=(metric == 1), seed=5100 + dim + bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    assert _front_taken(idx, 1, top_k, nprobe) == (rot == 1)  # the matrix rotator is O(D^2) per query: k_prep serves it
+    assert not _front_taken(idx, 64, top_k, nprobe)           # batches keep the GEMM
+    for nq in (1, 3, 8):
+        q = make_dataset(nq, dim, max(nlist // 4, 1), 5200 + nq, normalize=(metric == 1), uniform=uniform)
+        ids, sc, cnt = _compare(built, idx, q, top_k, nprobe)
+        idx.set_option("latency_path", 0)
+        ids0, sc0, cnt0, _ = idx.batch_search_raw(q, rq.SearchParams(top_k, nprobe))
+        idx.set_option("latency_path", 1)
+        assert np.array_equal(ids, ids0) and np.array_equal(cnt, cnt0) and np.array_equal(sc.view(np.uint32), sc0.view(np.uint32))
+    idx.close()
+
+
+STAGE_CASES = [
+    pytest.param(8000, 128, 64, 7, 0, 16, id="d128_7bit_L2"),
+    pytest.param(6000, 960, 48, 7, 0, 12, id="d960_7bit_L2"),
+    pytest.param(6000, 960, 48, 3, 1, 16, id="d960_3bit_IP"),
+    pytest.param(3000, 100, 24, 3, 1, 6, id="kac_d100_pad128_3bit_IP"),
+    pytest.param(1500, 40, 12, 3, 0, 12, id="kac_d40_trunc32_3bit_L2"),
+]
+
+
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,nprobe", STAGE_CASES)
+def test_latency_front_stage_outputs(n, dim, nlist, bits, metric, nprobe):
+    """Rotated query, LUT bytes, query constants and the score of EVERY list (not only the probed ones) against the oracle's stage
+    functions, bit for bit; the constants the lazy selection derives its slack from (q1norm, exlo, exhi, amin, amax) against the
+    batch kernel's."""
+    import torch
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, rotator=1, normalize=(metric == 1), seed=5300 + dim + bits)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    nq, top_k = 5, 10
+    q = make_dataset(nq, dim, max(nlist // 4, 1), 5353, normalize=(metric == 1))
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(q).to(dev)
+    out = (torch.zeros(nq, top_k, dtype=torch.int64, device=dev), torch.zeros(nq, top_k, dtype=torch.float32, device=dev),
+           torch.zeros(nq, dtype=torch.int32, device=dev))
+    st = torch.cuda.Stream(dev)
+    D = built.padded_dim
+    Dc = (D + 63) // 64 * 64
+    taps = {}
+    for lat in (0, 1):
+        idx.set_option("latency_path", lat)
+        torch.cuda.synchronize(dev)
+        idx.search_batch_device(qd.data_ptr(), nq, dim, top_k, nprobe, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        taps[lat] = (idx.debug_copy_workspace(st.cuda_stream, "rot", np.empty((nq, D), np.float32)),
+                     idx.debug_copy_workspace(st.cuda_stream, "lut", np.empty((nq, Dc * 4), np.uint8)),
+                     idx.debug_copy_workspace(st.cuda_stream, "consts", np.empty((nq, 12), np.float32)),
+                     idx.debug_copy_workspace(st.cuda_stream, "scores", np.empty((nq, nlist), np.float32)),
+                     out[0].cpu().numpy().copy(), out[1].cpu().numpy().copy(), out[2].cpu().numpy().copy())
+    rot_d, lut_d, consts_d, scores_d = taps[1][:4]
+    assert np.array_equal(rot_d.view(np.uint32), taps[0][0].view(np.uint32)) and np.array_equal(lut_d, taps[0][1])
+    assert np.array_equal(consts_d.view(np.uint32), taps[0][2].view(np.uint32)), "query constants differ from k_prep_wave's"
+    for a, b in zip(taps[0][4:], taps[1][4:]):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    for i in range(nq):
+        r = oracle.rotate(built, q[i])
+        assert np.array_equal(r.view(np.uint32), rot_d[i].view(np.uint32))
+        lut, delta, sum_vl = oracle.query_lut(r)
+        assert np.array_equal(lut_d[i].reshape(Dc // 4, 16)[np.arange(D // 4) ^ 1], lut.reshape(D // 4, 16))
+        qc = oracle.query_precompute(r, built.hdr.ex_bits)
+        want = np.array([delta, sum_vl, qc.k1x_sum_q, qc.kbx_sum_q, qc.binary_scale, qc.query_norm], np.float32)
+        assert np.array_equal(consts_d[i, :6].view(np.uint32), want.view(np.uint32))
+        for cid in range(nlist):  # (IP: the selection overwrites the scores of the lists it scans with their distances — skip those)
+            c = built.centroid(cid)
+            dist = np.float32(oracle.lib().ref_l2_distance_sqr(r.ctypes.data, c.ctypes.data, D))
+            dot = np.float32(oracle.lib().ref_dot(r.ctypes.data, c.ctypes.data, D))
+            got = scores_d[i, cid]
+            assert got == (dist if metric == 0 else dot) or (metric == 1 and got == dist), (i, cid, got, dist, dot)
+    idx.close()
+
+
+def test_latency_path_degenerate_queries():
+    """Zero, huge, NaN and Inf queries through the latency path: whatever the batch path returns (itself compared with the oracle
+    by test_degenerate_queries), bit for bit."""
+    data, built = build_index(n=4000, dim=128, nlist=32, total_bits=7, seed=5400)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    base = make_dataset(8, 128, 8, 5401)
+    qs = base.copy()
+    qs[0] = 0.0
+    qs[1] *= 1e30
+    qs[2, 5] = np.nan
+    qs[3, 7] = np.inf
+    qs[4, 9] = -np.inf
+    qs[5] = 1e-30
+    for nq in (1, 8):
+        for first in range(0, 8, nq):
+            q = qs[first:first + nq]
+            a = idx.batch_search_raw(q, rq.SearchParams(10, 8), want_diag=True)
+            idx.set_option("latency_path", 0)
+            b = idx.batch_search_raw(q, rq.SearchParams(10, 8), want_diag=True)
+            idx.set_option("latency_path", 1)
+            for x, y in zip(a, b):
+                assert np.array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8)), (nq, first)
+    rc, oids, osc, ocnt, _ = oracle.search_batch(built, qs[:2], 10, 8)
+    ids, sc, cnt, _ = idx.batch_search_raw(qs[:2], rq.SearchParams(10, 8))
+    assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)
+    idx.close()

@@ -21,7 +21,7 @@ for kv in a.option:
     k, v = kv.split("=")
     idx.set_option(k, int(v))
 q = mix.draw(4096, 20260102).cpu().numpy()
-for nq in (1, 8, 64, 256):
+for nq in [int(v) for v in os.environ.get('LAT_PROBE_NQ', '1,8,64,256').split(',')]:
     nsets = 16
     pin = []
     for j in range(nsets):
@@ -32,7 +32,7 @@ for nq in (1, 8, 64, 256):
     for j in range(nsets):
         call(j)
     ts = []
-    for r in range(200):
+    for r in range(int(os.environ.get('LAT_PROBE_CALLS', '200'))):
         t0 = time.perf_counter(); call(r % nsets); ts.append(time.perf_counter() - t0)
     ts = np.array(ts) * 1e6
     idx.profile_begin()

@@ -10,11 +10,15 @@ dev = torch.device("cuda", 0)
 mix = bench.Mixture(torch, dev, a.dim, a.nlist, 'mixture_id32', False)
 x = mix.draw(a.n, 20260105)
 cent, assign = bench.kmeans_gpu(torch, x, a.nlist, 6, 20260103)
-built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits, 0, 1, 20260104, True)
-idx = rq.IvfRabitqIndex.from_built(built)
+xs = mix.draw(max(2 * a.nlist, 8192), 99).cpu().numpy()  # the device encoder (a small CPU build only supplies the header, rotator and t_const)
+small = rq.builder.train_with_clusters(xs, cent.cpu().numpy(), (np.arange(len(xs)) % a.nlist).astype(np.uint32), a.bits, 0, 1, 20260104, True)
+idx = rq.IvfRabitqIndex.build_on_device(small.hdr_ptr, cent.cpu().numpy(), x.data_ptr(), assign.to(torch.int32).contiguous().data_ptr(), a.n, small.t_const)
+del x
 qds = [mix.draw(a.batch, 20260102 + i).contiguous() for i in range(3)]
 s = torch.cuda.Stream(dev)
 o = (torch.zeros(a.batch, a.top_k, dtype=torch.int64, device=dev), torch.zeros(a.batch, a.top_k, dtype=torch.float32, device=dev), torch.zeros(a.batch, dtype=torch.int32, device=dev))
+for kv in a.option:
+    idx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for qd in qds:
     idx.search_batch_device(qd.data_ptr(), a.batch, a.dim, a.top_k, a.nprobe, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), stream=s.cuda_stream)
 torch.cuda.synchronize(dev)
@@ -32,7 +36,7 @@ if os.environ.get("SEL_MODE") == "2":
     st = ((st - st.min()) & 0xffffffff) * 16
     print("starts: min 0 p50 %d p90 %d max %d ; duration mean %d p99 %d max %d ; last end %d" % (np.percentile(st, 50), np.percentile(st, 90), st.max(), du.mean(), np.percentile(du, 99), du.max(), (st + du).max()))
     order = np.argsort(st)
-    print("start of WG #0,256,512,768,1023 in start order:", st[order][[0, 256, 512, 768, 1023]])
+    if a.batch >= 1024: print("start of WG #0,256,512,768,1023 in start order:", st[order][[0, 256, 512, 768, 1023]])
     sys.exit(0)
 if os.environ.get("SEL_MODE") == "4":  # -DRBQ_SEL_STAMPS=4: sub-phases of the lazy branch, 128-cycle units
     for t, nme in enumerate(["approx sort", "certain members (z0)", "head scoring", "T_ub", "classification", "todo scoring", "membership+compaction+sort"]):

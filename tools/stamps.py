@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 mix = bench.Mixture(torch, dev, a.dim, a.nlist, 'mixture_id32', False)
 x = mix.draw(a.n, 20260105)
 cent, assign = bench.kmeans_gpu(torch, x, a.nlist, 6, 20260103)
-if a.n <= 2_000_000:
+if a.n <= 100_000:
     built = rq.builder.train_with_clusters(x.cpu().numpy(), cent.cpu().numpy(), assign.cpu().numpy().astype(np.uint32), a.bits, 0, 1, 20260104, True)
     idx = rq.IvfRabitqIndex.from_built(built)
 else:  # large index: the device encoder (a small CPU build only supplies the header, rotator and t_const)
@@ -23,6 +23,12 @@ idx.set_option('host_subbatch', 1 << 20)  # one sub-batch: the diag slots carry 
 for q in qs + ([qs[-1]] if os.environ.get('STAMPS_WARM') == '1' else []):  # the last batch is cold: nothing of it is in the caches (STAMPS_WARM=1: run it again, warm)
     ids, sc, cnt, diag = idx.batch_search_raw(q, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)
 d = diag.astype(np.uint64)
+if a.batch < 16:  # small calls (the latency regime): the stamps of 32 separate calls, each on queries the caches have not seen
+    rows = []
+    for i in range(32):
+        qi = mix.draw(a.batch, 20260200 + i).cpu().numpy()
+        rows.append(idx.batch_search_raw(qi, rq.SearchParams(a.top_k, a.nprobe), want_diag=True)[3])
+    d = np.concatenate(rows).astype(np.uint64)
 if os.environ.get('RBQ_STAMPS_MODE') == '3':
     lo = lambda c: (d[:, c] & 0xffffffff).astype(np.float64).mean(); hi = lambda c: (d[:, c] >> 32).astype(np.float64).mean()
     print('scanner wave 0 cycles/query: lookups %.0f  waitA %.0f  live tiles %.1f  survivors %.0f  fill %.0f  heavy tiles %.1f' % (lo(0), hi(0), lo(1), hi(1), lo(2), hi(2)))
