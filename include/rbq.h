@@ -250,6 +250,9 @@ void rbq_profile_set_sampling(rbq_index* idx, uint32_t every);
 /* Number of queries (since creation) whose probe selection fell back from the MFMA shortlist to the
  * all-lists canonical ranking (shortlist overflow / non-finite scores). Diagnostic. */
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* idx);
+/* tie log of k_scan (queries whose result depends on the layout of the reference's BinaryHeap, src/ivf.rs:904-931, replay their logged
+   candidates instead of their lists): out4 = replays, log entries replayed, real heap operations among them, logs that overflowed */
+void rbq_debug_tie_log_stats(const rbq_index* idx, uint64_t* out4);
 /* Diagnostic: which kernel instantiation each stage (prep, rank, select, scan) launches for a call of nq queries with this top_k /
  * nprobe on this index, and what it occupies: out[stage][6] = workgroups, threads per workgroup, VGPRs per lane, LDS bytes per
  * workgroup (static + dynamic), scratch bytes per lane, 0.  Nothing is launched.  bench.py's `regime` object is built from it. */

@@ -114,13 +114,13 @@ struct PinBuf { // page-locked host staging
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window, audit_dead;
+    DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window, audit_dead, tie_log;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
     bool latency_first = false; // this launch chain belongs to a host call that waits for it (rbq_search_batch below kHostWaveMinQueries)
     void release() {
         for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
-                          &heap_ws, &key_window, &audit_dead})
+                          &heap_ws, &key_window, &audit_dead, &tie_log})
             b->release();
         h_in.release(); h_out.release();
         if (done) (void)hipEventDestroy(done);
@@ -265,6 +265,7 @@ struct Replica {
     bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     int host_wave_policy = 0;  // option host_wave_policy (see search_host)
+    bool tie_log = true;       // option tie_log: k_scan logs the candidates it refines; a tied query replays the log (scan.hpp)
     int latency_path = 1;      // option latency_path: small calls (see kLatMaxQueries) take the latency-first front (latency.hpp); 0 = never
     int rank_tile = 0;         // option rank_tile: tile of the split-bf16 ranking GEMM (0 = by problem size)
     uint32_t stage_mask = 0xf; // DIAGNOSTIC (option stage_mask): bit s = launch stage s (prep, rank, select, scan); a skipped stage leaves the
@@ -477,8 +478,9 @@ int finish_replica(Replica* ix, const std::vector<uint32_t>& ln) {
                                   (const float*)ix->fres_ex.p, (const float*)ix->centroids.p, (const BlockSummary*)ix->bsum.p,
                                   (const uint32_t*)ix->list_gb0.p, (const uint32_t*)ix->list_n.p, nlist, D, ix->Dc, ix->ex_bits,
                                   (BlockSummaryEx*)ix->bsumx.p, (BlockSummary*)ix->lsum.p, 0));
-    if ((rc = alloc_arr(ix->fallbacks, 16))) return rc;   // [0] rank fallbacks, [1] heap restarts, [2] exact-head guard trips, [3] exact-head evaluations
-    HIP_TRY(hipMemset(ix->fallbacks.p, 0, 16));
+    if ((rc = alloc_arr(ix->fallbacks, 32))) return rc;   // [0] rank fallbacks, [1] heap restarts, [2] exact-head guard trips, [3] exact-head evaluations,
+                                                          // [4..7] tie log: replays, entries replayed, real heap operations, overflowed logs
+    HIP_TRY(hipMemset(ix->fallbacks.p, 0, 32));
     if ((rc = alloc_arr(ix->prof, (size_t)kProfStripes * kProfSlots * 8))) return rc;
     HIP_TRY(hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8));
     const char* e = std::getenv("RBQ_EXACT_RANK");
@@ -550,7 +552,7 @@ int clone_replica(const Replica* src, int dev, Replica** out) {
         if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, std::string("replicating the index: ") + hipGetErrorString(e)); }
         d->bytes = s->bytes;
     }
-    hipError_t e = hipMemset(ix->fallbacks.p, 0, 16);
+    hipError_t e = hipMemset(ix->fallbacks.p, 0, 32);
     if (e == hipSuccess) e = hipMemset(ix->prof.p, 0, (size_t)kProfStripes * kProfSlots * 8);
     if (e != hipSuccess) { free_replica(ix); return fail(RBQ_DEVICE, hipGetErrorString(e)); }
     *out = ix;
@@ -1105,6 +1107,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.no_block_bound = ix->no_block_bound ? 1u : 0u;
     P.exact_heap = ix->exact_heap ? 1u : 0u;
     P.heap_restarts = (unsigned int*)ix->fallbacks.p + 1;
+    P.tie_stats = (unsigned int*)ix->fallbacks.p + 4;
     P.mstg = mstg ? 1u : 0u;
     P.prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     P.dead_skipped = d_dead_skipped;
@@ -1115,6 +1118,14 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     // four waves finish a 1024-query launch in 0.10 ms, k_scanw's single wave in 0.14 ms) until the call is large enough for the rate
     // to matter more than the last chain's latency.
     P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries && !ix->no_block_bound && !w->latency_first)) ? 1u : 0u;
+    // tie log (k_scan, no diagnostics, top-k in registers): a tied query replays its logged candidates instead of its lists
+    P.tie_log = nullptr; P.tie_log_cap = 0;
+    if (ix->tie_log && !P.wave_kernel && !d_diag && !mstg && top_k >= 1 && top_k <= kTopKRegMax && !ix->exact_heap) {
+        const uint32_t cap = top_k < 64u ? 4096u : 16384u;
+        if ((uint64_t)nq * cap * 12u <= (1ull << 30) && w->tie_log.ensure((size_t)nq * cap * 12u) == RBQ_OK) {
+            P.tie_log = (uint32_t*)w->tie_log.p; P.tie_log_cap = cap;
+        }
+    }
     P.heap_ws = nullptr;
     if (top_k > kTopKMax || scan_lds_bytes(ix->Dc, ix->D, P.ex_bits, top_k) > kLdsPerWorkgroupMax) { // the heap does not fit the LDS
         int rc = w->heap_ws.ensure((size_t)nq * 2 * ((size_t)top_k + 1) * 4);
@@ -1955,6 +1966,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "rank_tile")) ix->rank_tile = value;
         else if (!std::strcmp(name, "host_wave_policy")) ix->host_wave_policy = value;
         else if (!std::strcmp(name, "latency_path")) ix->latency_path = value;
+        else if (!std::strcmp(name, "tie_log")) ix->tie_log = value != 0;
         else if (!std::strcmp(name, "stage_mask")) ix->stage_mask = (uint32_t)value & 0xfu;
         else if (!std::strcmp(name, "scan_wave")) ix->scan_wave = value < 0 ? scan_wave_default() : (value > 2 ? 2 : value);
         else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;
@@ -1997,6 +2009,7 @@ static uint64_t read_counter(const rbq_index* h, int slot) {
     return tot;
 }
 uint64_t rbq_debug_rank_fallbacks(const rbq_index* h) { return read_counter(h, 0); }
+void rbq_debug_tie_log_stats(const rbq_index* h, uint64_t* out4) { if (out4) for (int i = 0; i < 4; ++i) out4[i] = read_counter(h, 4 + i); }
 uint64_t rbq_debug_head_exact_guard_trips(const rbq_index* h) { return read_counter(h, 2); }
 uint64_t rbq_debug_head_exact_evaluations(const rbq_index* h) { return read_counter(h, 3); }
 // Which kernel instantiation each of the four stages launches for a call of this shape, and what it occupies.

@@ -72,6 +72,23 @@ __device__ __forceinline__ void look8(uint32_t& acc, uint32_t x, lds_lut_ptr p) 
 #ifndef RBQ_CODE_WIN
 #define RBQ_CODE_WIN 2
 #endif
+// per-lane byte offsets of the code loads pass through an empty asm where they are used (see load_codes)
+#ifndef RBQ_ANTIHOIST
+#define RBQ_ANTIHOIST 1
+#endif
+#if RBQ_ANTIHOIST == 1
+#define RBQ_OPAQUE(x) asm volatile("" : "+v"(x))
+#define RBQ_OPAQUE2(x) asm volatile("" : "+v"(x))
+#elif RBQ_ANTIHOIST == 2
+#define RBQ_OPAQUE(x) asm("" : "+v"(x))
+#define RBQ_OPAQUE2(x) asm("" : "+v"(x))
+#elif RBQ_ANTIHOIST == 3
+#define RBQ_OPAQUE(x) asm volatile("" : "+v"(x))
+#define RBQ_OPAQUE2(x)
+#else
+#define RBQ_OPAQUE(x)
+#define RBQ_OPAQUE2(x)
+#endif
 constexpr int kCodeWin = RBQ_CODE_WIN;
 template <int DT>
 struct CodeRegs {
@@ -86,13 +103,22 @@ __device__ __forceinline__ void load_codes(CodeRegs<DT>& c, const uint8_t* __res
     const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
 #pragma unroll
     for (int g = 0; g < CodeRegs<DT>::W && g < (DT >> 7); ++g) c.x[g] = cp[g * 32];
-    if (DT & 64) c.tail = *(reinterpret_cast<const uint2*>(blk + (DT >> 7) * 512) + l32);
+    if (DT & 64) {
+        // (the lane's byte offset is formed HERE, behind an empty asm: hoisted out of the tile loop it is a 64-bit loop invariant per
+        // lane, and in the instantiations that sit at their register limit that pair was the value hipcc chose to spill — a scratch
+        // reload with its s_waitcnt vmcnt(0) between the code loads of every tile)
+        uint32_t off = l32 * 8u;
+        RBQ_OPAQUE(off);
+        c.tail = *reinterpret_cast<const uint2*>(blk + (DT >> 7) * 512 + off);
+    }
 }
 
 template <int DT>
 __device__ __forceinline__ uint32_t lookup_codes(CodeRegs<DT>& c, const uint8_t* __restrict__ blk, uint32_t l32, lds_lut_ptr lut) {
     constexpr int G = DT >> 7, W = CodeRegs<DT>::W;
-    const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
+    uint32_t off = l32 * 16u; // (formed here, not hoisted: see load_codes)
+    RBQ_OPAQUE2(off);
+    const uint4* cp = reinterpret_cast<const uint4*>(blk + off);
     uint32_t acc = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -778,6 +804,215 @@ struct SortedRun {
     }
 };
 
+// ---- the same BinaryHeap with LANE-PARALLEL primitives -------------------------------------------------------------------------
+// RegHeap walks a sift level by level through v_readlane / compare-and-select (every hop a VALU -> SGPR -> VALU round trip:
+// ~2-3 k cycles per push + pop at top_k = 100).  ParHeap holds the same array (entry g in lane g % 64 of register g / 64, raw
+// distance bits) and gets the same result — Rust's std BinaryHeap, operation for operation — from what the operations DO to the array:
+//   push(x)  sift_up moves x up its fixed ancestor chain while x > parent: the ancestors with key < x (a bottom prefix of the chain,
+//            by the heap property) each move to their path child, x takes the topmost one's place.  One parallel step: every slot on
+//            the chain looks at its parent.
+//   pop()    the last element e replaces the root, sift_down_to_bottom takes the larger child at every level (`<=`: the right one on
+//            equal keys) down to a leaf, sift_up brings e back up while e > parent.  Net effect: along that larger-child path the
+//            nodes p_1 .. p_m with key >= e (a top prefix: keys fall along the path) move up one level, e lands in p_m's place, and
+//            everything below is put back where it was.  So: every slot computes its larger child in parallel (children fetched with
+//            ds_bpermute), a short scalar chain follows the path while key >= e, one parallel step applies it.
+// ~4x fewer cycles per real heap operation; used by the tie log's replay (own function, own register allocation).
+template <int TR>
+struct ParHeap {
+    int kd[TR];      // raw distance bits of entry 64 r + lane
+    uint32_t ks[TR]; // slots
+    uint32_t len;    // uniform
+    static constexpr uint32_t kNone = 0xffffffffu;
+    static __device__ __forceinline__ int key(int b) { return HeapOps::key(b); }
+    // value of entry idx (per lane; idx < 64 TR) of an array held in TR registers; S0..S1: the source registers idx can lie in
+    template <typename T>
+    __device__ __forceinline__ T fetch(const T (&a)[TR], uint32_t idx, int s0, int s1) const {
+        T v = a[0];
+        const int addr = (int)((idx & 63u) << 2);
+#pragma unroll
+        for (int s = 0; s < TR; ++s)
+            if (s >= s0 && s <= s1) {
+                const T t = (T)__builtin_amdgcn_ds_bpermute(addr, (int)a[s]);
+                v = (idx >> 6) == (uint32_t)s ? t : v;
+            }
+        return v;
+    }
+    template <typename T>
+    __device__ __forceinline__ T at(const T (&a)[TR], uint32_t i) const { // uniform index
+        const uint32_t r = HeapOps::uni(i >> 6);
+        T v = a[0];
+#pragma unroll
+        for (int k = 1; k < TR; ++k) v = r == (uint32_t)k ? a[k] : v;
+        return (T)__builtin_amdgcn_readlane((int)v, (int)HeapOps::uni(i & 63u));
+    }
+    // is g a proper ancestor of slot n in the implicit tree?
+    static __device__ __forceinline__ bool is_anc(uint32_t g, uint32_t n) {
+        const int t = (int)__builtin_clz(g + 1u) - (int)__builtin_clz(n + 1u);
+        return g < n && t > 0 && ((n + 1u) >> t) == g + 1u;
+    }
+    __device__ __forceinline__ void push(int xb, uint32_t xs, uint32_t lane) {
+        const uint32_t n = HeapOps::uni(len);
+        const int kx = key(xb);
+        int nk[TR];
+        uint32_t ns[TR];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const uint32_t g = (uint32_t)r * 64u + lane;
+            const bool on_path = g == n || is_anc(g, n);
+            const uint32_t par = g ? (g - 1u) >> 1 : 0u; // (lies in register <= r)
+            const int pk = fetch(kd, par, (64 * r) / 128 > 0 ? (64 * r - 1) / 128 : 0, (64 * r + 62) / 128);
+            const uint32_t ps = fetch(ks, par, (64 * r) / 128 > 0 ? (64 * r - 1) / 128 : 0, (64 * r + 62) / 128);
+            const bool parent_moved = on_path && g > 0u && key(pk) < kx;                 // the parent is an ancestor that x passes
+            const bool takes_x = on_path && !parent_moved && (g == n || key(kd[r]) < kx); // the top of the moved chain (or the slot itself)
+            nk[r] = parent_moved ? pk : (takes_x ? xb : kd[r]);
+            ns[r] = parent_moved ? ps : (takes_x ? xs : ks[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) { kd[r] = nk[r]; ks[r] = ns[r]; }
+        len = n + 1u;
+    }
+    __device__ __forceinline__ void pop(uint32_t lane) {
+        const uint32_t n = HeapOps::uni(len) - 1u; // the last element's index = the new length
+        len = n;
+        if (n == 0u) return;
+        const int eb = at(kd, n);
+        const uint32_t es = at(ks, n);
+        const int ke = key(eb);
+        uint32_t big[TR];
+        int bk[TR];
+        uint32_t bs[TR];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            big[r] = kNone; bk[r] = 0; bs[r] = 0u;
+            if (128 * r + 1 < 64 * TR) { // (slots of this register can have children inside the array)
+                const uint32_t g = (uint32_t)r * 64u + lane, cl = 2u * g + 1u, cr = 2u * g + 2u;
+                const int s0 = 2 * r, s1 = 2 * r + 2 < TR ? 2 * r + 2 : TR - 1;
+                const int kl = fetch(kd, cl & (64u * TR - 1u), s0, s1), kr = fetch(kd, cr & (64u * TR - 1u), s0, s1);
+                const uint32_t sl = fetch(ks, cl & (64u * TR - 1u), s0, s1), sr = fetch(ks, cr & (64u * TR - 1u), s0, s1);
+                const bool hasl = cl < n, right = cr < n && key(kl) <= key(kr); // `hole.get(child) <= hole.get(child + 1)`: the right one
+                big[r] = hasl ? (right ? cr : cl) : kNone;
+                bk[r] = right ? kr : kl;
+                bs[r] = right ? sr : sl;
+            }
+        }
+        unsigned long long take[TR];
+#pragma unroll
+        for (int r = 0; r < TR; ++r) take[r] = 0ull;
+        uint32_t p = 0;
+        for (;;) { // the larger-child path from the root while its nodes stay above e (`e <= parent` ends the closing sift_up)
+            const uint32_t c = at(big, p);
+            if (c == kNone) break;
+            if (!(key(at(bk, p)) >= ke)) break;
+#pragma unroll
+            for (int r = 0; r < TR; ++r) if ((p >> 6) == (uint32_t)r) take[r] |= 1ull << (p & 63u);
+            p = c;
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const bool tk = (take[r] >> lane) & 1ull, isp = (uint32_t)r * 64u + lane == p;
+            kd[r] = tk ? bk[r] : (isp ? eb : kd[r]);
+            ks[r] = tk ? bs[r] : (isp ? es : ks[r]);
+        }
+    }
+    // some node of the root-to-slot-K path equals its off-path child (heap full: len == K)
+    __device__ __forceinline__ bool path_tie(uint32_t K, uint32_t lane) const {
+        bool t = false;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (128 * r + 1 < 64 * TR) {
+                const uint32_t g = (uint32_t)r * 64u + lane, cl = 2u * g + 1u, cr = 2u * g + 2u;
+                const int s0 = 2 * r, s1 = 2 * r + 2 < TR ? 2 * r + 2 : TR - 1;
+                const int kl = fetch(kd, cl & (64u * TR - 1u), s0, s1), kr = fetch(kd, cr & (64u * TR - 1u), s0, s1);
+                const bool anc = is_anc(g, K);
+                const bool left_on_path = cl == K || is_anc(cl, K); // (else the right child is the path child)
+                const uint32_t off = left_on_path ? cr : cl;
+                t |= anc && off < K && kd[r] == (left_on_path ? kr : kl);
+            }
+        }
+        return __ballot(t) != 0ull;
+    }
+};
+
+// The reference's prune / push / pop loop (src/ivf.rs:2054-2126) over a query's logged candidates, with the BinaryHeap emulation: what a
+// tied query runs instead of scanning its lists again (k_scan, `tie_log`).  One wave; the heap lives in registers (ParHeap) or, for
+// top_k = 64 TR exactly, in LDS.  Returns the heap (everything by value: an argument passed by reference would pin the caller's top-k
+// registers to memory for the whole kernel); `len` of the result is the heap's length in both cases.
+template <int TR>
+__device__ __attribute__((noinline)) RegHeap<TR> tie_log_replay(float* heap_d, uint32_t* heap_s, const uint32_t* tlog, uint32_t log_n,
+                                                                uint32_t top_k, bool reg_heap, uint32_t lane, unsigned int* stats) {
+    uint32_t n_real = 0;
+#ifdef RBQ_TIE_TIMING
+    const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+#endif
+    ParHeap<TR> ph;
+#pragma unroll
+    for (int r = 0; r < TR; ++r) { ph.kd[r] = 0; ph.ks[r] = 0u; }
+    ph.len = 0u;
+    LdsHeap lh{heap_d, heap_s, 0};
+    // PUSH-THEN-POP IS THE IDENTITY.  Most evaluated candidates of a full heap lie above its root: the reference pushes them and pops
+    // them again (src/ivf.rs:2116-2126).  With Rust's BinaryHeap (sift_up; pop = swap the last element into the root,
+    // sift_down_to_bottom, sift_up) that pair leaves the array exactly as it was: the new key x > root climbs the path from slot k
+    // to the root, shifting the path's elements down by one; pop removes the element now in slot k, puts it in the root, and the hole
+    // walks back DOWN THE SAME PATH — at every path node the path child holds the node's own old value, which is >= the off-path
+    // child — restoring every element, and the displaced one ends where it came from.  The only way off the path is a comparison
+    // of EQUAL keys (`<=` picks the right child; the closing sift_up stops at `<=`), i.e. a path node whose old value equals its
+    // off-path child's.  `ptie` = some node of the (fixed: top_k is) root-to-slot-k path equals its off-path child (conservative);
+    // while it is false a candidate with key > root key is skipped in O(1); it is re-evaluated (lazily) after a real insertion.
+    bool ptie = false, ptie_valid = true;
+    auto lds_path_tie = [&]() -> bool {
+        bool t = false;
+        for (uint32_t c = top_k; c > 0;) {
+            const uint32_t par = (c - 1u) >> 1, sib = (c & 1u) ? c + 1u : c - 1u;
+            if (sib < top_k) t |= __float_as_int(heap_d[par]) == __float_as_int(heap_d[sib]);
+            c = par;
+        }
+        return t;
+    };
+    for (uint32_t c0 = 0; c0 < log_n; c0 += 64u) {
+        const uint32_t cn = log_n - c0 < 64u ? log_n - c0 : 64u;
+        int e_lb = 0, e_d = 0;
+        uint32_t e_s = 0;
+        if (lane < cn) { const uint32_t* e = tlog + (size_t)(c0 + lane) * 3u; e_lb = (int)e[0]; e_d = (int)e[1]; e_s = e[2]; }
+        for (uint32_t j = 0; j < cn; ++j) {
+            const float lb = __int_as_float(__builtin_amdgcn_readlane(e_lb, (int)j));
+            const int dbits = __builtin_amdgcn_readlane(e_d, (int)j);
+            const uint32_t hlen = reg_heap ? HeapOps::uni(ph.len) : lh.len;
+            const bool full = hlen == top_k;
+            const int rootb = !full ? 0x7f800000 : (reg_heap ? __builtin_amdgcn_readlane(ph.kd[0], 0) : __float_as_int(heap_d[0]));
+            if (lb >= __int_as_float(rootb)) continue;                  // `lower_bound >= distk`: skipped
+            if (!finite_f(__int_as_float(dbits))) continue;             // non-finite distance: dropped
+            if (full && HeapOps::key(dbits) > HeapOps::key(rootb)) {    // pushed and popped again: the heap is unchanged ...
+                if (!ptie_valid) { ptie = reg_heap ? ph.path_tie(top_k, lane) : lds_path_tie(); ptie_valid = true; }
+                if (!ptie) continue;                                    // ... unless equal keys sit on the path
+            }
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)e_s, (int)j);
+            ++n_real;
+            if (reg_heap) {
+                ph.push(dbits, slot, lane);
+                if (ph.len > top_k) ph.pop(lane);
+            } else {
+                if (lane == 0) {
+                    lh.push(__int_as_float(dbits), slot);
+                    if (lh.len > top_k) lh.pop();
+                }
+                lh.len = (uint32_t)__builtin_amdgcn_readfirstlane((int)lh.len);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            ptie_valid = false;
+        }
+    }
+    if (stats && lane == 0) { atomicAdd(stats, 1u); atomicAdd(stats + 1, log_n); atomicAdd(stats + 2, n_real); }
+#ifdef RBQ_TIE_TIMING
+    if (stats && lane == 0) atomicAdd(stats + 3, (unsigned int)((__builtin_amdgcn_s_memtime() - tt0) >> 6)); // (diagnostic build: slot 3 = ticks / 64)
+#endif
+    RegHeap<TR> rh;
+    rh.hd = ph.kd[0]; rh.hs = ph.ks[0]; rh.xd = 0; rh.xs = 0u;
+#pragma unroll
+    for (int r = 1; r < TR; ++r) { rh.xd[r] = ph.kd[r]; rh.xs[r] = ph.ks[r]; }
+    rh.len = reg_heap ? ph.len : lh.len;
+    return rh;
+}
+
 #ifndef RBQ_REPLAY_PRIO
 #define RBQ_REPLAY_PRIO 3
 #endif
@@ -868,6 +1103,8 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
     uint32_t p_code = 0, p_meta = 0, p_pass = 1; // (candidates whose ex codes were fetched are counted in s_misc[7])
     const bool count_skips = P.diag != nullptr;
 
+    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // sorted run (SortedRun / RankRun) until a distance tie shows up
+    uint32_t* const tlog = P.tie_log ? P.tie_log + (size_t)q * P.tie_log_cap * 3u : nullptr; // tie log of this query (see `log_n` below)
     // group `g` (16 lanes) refines the survivor at queue position s_batch[g] of tile buffer `buf`.  The ex
     // factors are requested together with the code units, not after the dot product.
     auto refine_batch = [&](uint32_t buf, uint32_t nb, uint32_t g) {
@@ -1001,7 +1238,6 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
     // RankRun from top_k = 64; below, the one-register sorted run (RankRun there costs the hot kernel 20 bytes of scratch at
     // five waves per SIMD, and at top_k = 10 most candidates are rejected by one scalar compare anyway)
     constexpr bool kRank = TR > 1;
-    bool fast = top_k <= 64u * TR && !P.exact_heap && !P.mstg; // sorted run (SortedRun / RankRun) until a distance tie shows up
     RegHeap<TR> rh; // the replay wave's top-k registers: exact heap, or (same registers) the bag
     rh.hd = 0; rh.hs = 0u; rh.xd = 0; rh.xs = 0u; rh.len = 0u;
     if (kRank && fast) RankRun<TR>::clear(rh); // keys, empty lanes marked
@@ -1012,6 +1248,12 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
     // decides at the end of the stream whether the reference's result depends on the layout of its heap.
     constexpr bool kLazyTies = RBQ_SCAN_LAZY_TIES != 0;
     int amb_min = 0x7fffffff;
+    // TIE LOG: every candidate a refine batch takes (a superset, in stream order, of the ones the reference evaluates) is written to
+    // the query's log with its lower bound, refined distance and slot.  The reference's own loop over exactly these candidates —
+    // `lower_bound >= distk` -> skip, push, pop — is a function of that sequence alone (a candidate outside the log has
+    // lb >= a threshold that was already >= the reference's: skipped there too), so a tied query replays the log through the exact
+    // heap instead of scanning its lists again.
+    uint32_t log_n = 0; // replay wave, uniform: entries logged so far (may pass the capacity: then the log is not used)
     LdsHeap lh{heap_d, heap_s, 0};
 #ifdef RBQ_STAMPS
     unsigned long long st_total = __builtin_amdgcn_s_memtime(), st_heavy = 0, st_waitA = 0, st_look = 0, st_fill = 0, st_a, st_b, st_c;
@@ -1268,7 +1510,7 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
         } else {
             // ---------------------------------------------------------------- replay wave (uniform control flow)
             STAMP(r0);
-            if (tie_pending && lane == 0) s_restart = 1u;
+            if (tie_pending && !tlog && lane == 0) s_restart = 1u; // (with a tie log the pass runs to its end: the log must be complete)
             lds_barrier(); // A
             RSTAMP(rp_waitA);
             if (fast && s_restart) break;
@@ -1289,7 +1531,7 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
             // ones the reference evaluates, since the threshold only shrinks), refines them in parallel and then
             // replays the examined stretch against the running threshold.
             uint32_t n_ref_tile = 0; // candidates taken for refinement in this tile (traffic counter)
-            struct Batch { uint32_t p, np, ncol, e; unsigned long long mt; int v_lb; };
+            struct Batch { uint32_t p, np, ncol, e, logb; unsigned long long mt; int v_lb; };
             auto cur_distk = [&]() -> float {
                 if (fast) return rh.len < top_k ? INFINITY : __int_as_float(!kRank ? SortedRun<TR>::kth(rh.hd, rh.xd, rh.len, top_k) : bag_dk);
                 return reg_heap ? (rh.len < top_k ? INFINITY : __int_as_float(rh.d_at(0)))
@@ -1315,6 +1557,8 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
                     if (ex_bits && take) s_batch[rank] = s_list[i];
                     n_ref_tile += (uint32_t)__popcll(mt);
                     bt.p = p; bt.np = np; bt.ncol = (uint32_t)__popcll(mt); bt.e = e; bt.mt = mt; bt.v_lb = __float_as_int(lbv);
+                    bt.logb = log_n;
+                    if (tlog && fast) log_n += bt.ncol; // batches are collected in stream order (the replay may lag one batch behind)
                     return bt;
                 }
             };
@@ -1326,6 +1570,13 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
                 if ((bt.mt >> lane) & 1ull) { v_d = __float_as_int(q_d[bt.e]); v_s = q_slot[bt.e]; }
                 unsigned long long todo = bt.mt;
                 n_skip += (bt.np - bt.p) - bt.ncol;
+                if (tlog && fast) { // tie log: the batch's candidates, in stream order (one 12-byte store per taken lane)
+                    const uint32_t at = bt.logb + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(bt.mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bt.mt, 0u));
+                    if (((bt.mt >> lane) & 1ull) && at < P.tie_log_cap) {
+                        uint32_t* ent = tlog + at * 3u; // (three dword stores from one address: no register triple to find)
+                        ent[0] = (uint32_t)bt.v_lb; ent[1] = (uint32_t)v_d; ent[2] = v_s;
+                    }
+                }
 #if RBQ_STAMPS == 4
                 asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(v_d), "v"(v_s) : "memory");
                 RSTAMP(rp_x1); // the batch's distances have arrived from LDS
@@ -1519,7 +1770,18 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
         }
         tie_pending = __ballot(eq) != 0ull || (lenf == top_k && maxkey == amb_min);
     }
-    if (tie_pending && lane == 0) s_restart = 1u; // (a tie met in the last tile; lazy ties: decided by the final run)
+    if (!scanner && fast && tie_pending && tlog && log_n <= P.tie_log_cap) {
+        // the tied query: the reference's loop over the logged candidates with the BinaryHeap emulation (this wave alone; the
+        // scanners wait at barrier F).  The heap ends up where the re-scan would have left it.  (Not inlined: the cold path must not
+        // take part in the register allocation of the scan loop — it cost the top_k = 100 instantiation a spill inside every tile.)
+        __threadfence_block(); // (the log was written by this wave: its stores are complete before the loads below)
+        if (lane == 0 && P.heap_restarts) atomicAdd(P.heap_restarts, 1u);
+        rh = tie_log_replay<TR>(heap_d, heap_s, tlog, log_n, top_k, reg_heap, lane, P.tie_stats);
+        lh.len = rh.len;
+        fast = false; // (this wave only: the result is read from the heap below)
+        tie_pending = false;
+    }
+    if (tie_pending && lane == 0) { s_restart = 1u; if (tlog && P.tie_stats) atomicAdd(P.tie_stats + 3, 1u); } // (lazy ties: decided by the final run)
     lds_barrier(); // F: the replay wave has consumed the last tile
     if (!s_restart) break;
     __syncthreads(); // every wave has seen the flag

@@ -113,6 +113,12 @@ struct ScanParams {
     const uint32_t* dead_skipped; // [nq] vectors of probed lists that the probe selection proved skipped as a whole (they
                                   // never enter the stream; diagnostics add them to skipped_by_lower_bound), or null
     uint32_t wave_kernel;         // 1: k_scanw (one wave per query, scanw.hpp) where it serves the call; 0: k_scan (one workgroup per query)
+    // k_scan: log of the candidates the fast pass refined (lower bound, distance, slot — in stream order, tie_log_cap entries per
+    // query), or null.  A query whose result depends on the layout of the reference's BinaryHeap (equal distances) then replays the
+    // LOG through the exact heap instead of scanning its lists again; a log that overflowed falls back to the re-scan.
+    uint32_t* tie_log;
+    uint32_t tie_log_cap;
+    unsigned int* tie_stats;      // [4] counters: replays, entries replayed, real heap operations, overflowed logs (or null)
 };
 // traffic counters kept while a profile is open (rbq_profile_begin/end); [0] is written by the select kernels
 enum { kProfVectorsProbed = 0, kProfCodeBlocks = 1, kProfMetaBlocks = 2, kProfStreamEntries = 3, kProfExEvals = 4,

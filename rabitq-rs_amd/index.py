@@ -69,6 +69,8 @@ def lib():
         for n_ in ("rbq_debug_head_exact_evaluations", "rbq_debug_head_exact_guard_trips"):
             getattr(L, n_).restype = C.c_uint64
             getattr(L, n_).argtypes = [vp]
+        L.rbq_debug_tie_log_stats.restype = None
+        L.rbq_debug_tie_log_stats.argtypes = [vp, vp]
         L.rbq_debug_bounce_copies.restype = C.c_uint64
         L.rbq_debug_bounce_copies.argtypes = []
         L.rbq_index_build_device.restype = C.c_int
@@ -319,6 +321,12 @@ class IvfRabitqIndex:
     def head_exact_stats(self):
         """(queries whose probe selection ran the exact head evaluation, guard trips — must be 0)"""
         return int(lib().rbq_debug_head_exact_evaluations(self._h)), int(lib().rbq_debug_head_exact_guard_trips(self._h))
+
+    def tie_log_stats(self):
+        """k_scan's tie log: {replays, entries, heap_ops, overflows} since the index was created"""
+        out = np.zeros(4, np.uint64)
+        lib().rbq_debug_tie_log_stats(self._h, out.ctypes.data)
+        return dict(zip(("replays", "entries", "heap_ops", "overflows"), (int(v) for v in out)))
 
     def rank_fallbacks(self):
         return lib().rbq_debug_rank_fallbacks(self._h)

@@ -73,6 +73,13 @@ def run(batch, shapes, reps):
             t0 = time.perf_counter()
             call(r % NSETS, pinned)
             ts[r] = time.perf_counter() - t0
+        if os.environ.get("HOST_PROBE_PER_SET") and pinned:  # per query set: median call time, tied queries replayed from the log
+            rep = []
+            for j in range(NSETS):
+                a0 = idx.tie_log_stats(); call(j, pinned); a1 = idx.tie_log_stats()
+                rep.append("set %d: %.0f us, %d replays (%d entries, %d heap ops)" % (j, np.median(ts[j::NSETS]) * 1e6, a1["replays"] - a0["replays"],
+                           a1["entries"] - a0["entries"], a1["heap_ops"] - a0["heap_ops"]))
+            print("    " + "; ".join(rep), flush=True)
         call(0, pinned)
         got = np.ctypeslib.as_array(C.cast(pin[0][1], C.POINTER(C.c_uint64)), shape=(batch, top_k)) if pinned else out[0]
         return np.median(ts) * 1e6, np.percentile(ts, 10) * 1e6, bool(np.array_equal(got, want))
@@ -106,3 +113,4 @@ for nq_ in [int(t) for t in os.environ.get("HOST_PROBE_NQ", "1024,4096,256,64,1"
         run(nq_, shapes_of("HOST_PROBE_SHAPES", [(512, 2), (256, 4), (0, 0)]), 300)
     else:
         run(nq_, [(0, 0)], 300)
+print('tie log:', idx.tie_log_stats(), 'heap restarts', idx.heap_restarts())
