@@ -265,6 +265,7 @@ struct Replica {
     bool lazy_audit = false; // DIAGNOSTIC (option lazy_audit): the select kernel exports the lists it drops as a whole (workspace "audit_dead")
     bool lazy_select = true; // probe selection drops lists that are provably skipped as a whole (rank_mfma.hpp)
     int host_wave_policy = 0;  // option host_wave_policy (see search_host)
+    uint32_t tie_log_cap = 0;  // TEST ONLY (option tie_log_cap): entries per query of the tie log (0 = the default sizes)
     bool tie_log = true;       // option tie_log: k_scan logs the candidates it refines; a tied query replays the log (scan.hpp)
     int latency_path = 1;      // option latency_path: small calls (see kLatMaxQueries) take the latency-first front (latency.hpp); 0 = never
     int rank_tile = 0;         // option rank_tile: tile of the split-bf16 ranking GEMM (0 = by problem size)
@@ -1121,7 +1122,7 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     // tie log (k_scan, no diagnostics, top-k in registers): a tied query replays its logged candidates instead of its lists
     P.tie_log = nullptr; P.tie_log_cap = 0;
     if (ix->tie_log && !P.wave_kernel && !d_diag && !mstg && top_k >= 1 && top_k <= kTopKRegMax && !ix->exact_heap) {
-        const uint32_t cap = top_k < 64u ? 4096u : 16384u;
+        const uint32_t cap = ix->tie_log_cap ? ix->tie_log_cap : (top_k < 64u ? 4096u : 16384u); // (option tie_log_cap: tests of the overflow path)
         if ((uint64_t)nq * cap * 12u <= (1ull << 30) && w->tie_log.ensure((size_t)nq * cap * 12u) == RBQ_OK) {
             P.tie_log = (uint32_t*)w->tie_log.p; P.tie_log_cap = cap;
         }
@@ -1967,6 +1968,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "host_wave_policy")) ix->host_wave_policy = value;
         else if (!std::strcmp(name, "latency_path")) ix->latency_path = value;
         else if (!std::strcmp(name, "tie_log")) ix->tie_log = value != 0;
+        else if (!std::strcmp(name, "tie_log_cap")) ix->tie_log_cap = value > 0 ? (uint32_t)value : 0u;
         else if (!std::strcmp(name, "stage_mask")) ix->stage_mask = (uint32_t)value & 0xfu;
         else if (!std::strcmp(name, "scan_wave")) ix->scan_wave = value < 0 ? scan_wave_default() : (value > 2 ? 2 : value);
         else if (!std::strcmp(name, "profile_counters")) ix->profile_counters = value != 0;

@@ -819,7 +819,7 @@ struct SortedRun {
 // ~4x fewer cycles per real heap operation; used by the tie log's replay (own function, own register allocation).
 template <int TR>
 struct ParHeap {
-    int kd[TR];      // raw distance bits of entry 64 r + lane
+    int kd[TR];      // KEY (HeapOps::key of the distance bits: plain signed compares; its own inverse) of entry 64 r + lane
     uint32_t ks[TR]; // slots
     uint32_t len;    // uniform
     static constexpr uint32_t kNone = 0xffffffffu;
@@ -850,9 +850,8 @@ struct ParHeap {
         const int t = (int)__builtin_clz(g + 1u) - (int)__builtin_clz(n + 1u);
         return g < n && t > 0 && ((n + 1u) >> t) == g + 1u;
     }
-    __device__ __forceinline__ void push(int xb, uint32_t xs, uint32_t lane) {
+    __device__ __forceinline__ void push(int kx, uint32_t xs, uint32_t lane) { // kx: the KEY of the new distance
         const uint32_t n = HeapOps::uni(len);
-        const int kx = key(xb);
         int nk[TR];
         uint32_t ns[TR];
 #pragma unroll
@@ -862,9 +861,9 @@ struct ParHeap {
             const uint32_t par = g ? (g - 1u) >> 1 : 0u; // (lies in register <= r)
             const int pk = fetch(kd, par, (64 * r) / 128 > 0 ? (64 * r - 1) / 128 : 0, (64 * r + 62) / 128);
             const uint32_t ps = fetch(ks, par, (64 * r) / 128 > 0 ? (64 * r - 1) / 128 : 0, (64 * r + 62) / 128);
-            const bool parent_moved = on_path && g > 0u && key(pk) < kx;                 // the parent is an ancestor that x passes
-            const bool takes_x = on_path && !parent_moved && (g == n || key(kd[r]) < kx); // the top of the moved chain (or the slot itself)
-            nk[r] = parent_moved ? pk : (takes_x ? xb : kd[r]);
+            const bool parent_moved = on_path && g > 0u && pk < kx;                 // the parent is an ancestor that x passes
+            const bool takes_x = on_path && !parent_moved && (g == n || kd[r] < kx); // the top of the moved chain (or the slot itself)
+            nk[r] = parent_moved ? pk : (takes_x ? kx : kd[r]);
             ns[r] = parent_moved ? ps : (takes_x ? xs : ks[r]);
         }
 #pragma unroll
@@ -875,34 +874,31 @@ struct ParHeap {
         const uint32_t n = HeapOps::uni(len) - 1u; // the last element's index = the new length
         len = n;
         if (n == 0u) return;
-        const int eb = at(kd, n);
+        const int ke = at(kd, n);
         const uint32_t es = at(ks, n);
-        const int ke = key(eb);
+        // every slot's larger child — if that child stays above e (`e <= parent` ends the closing sift_up), else none: the scalar
+        // chain below then needs ONE readlane per level
         uint32_t big[TR];
         int bk[TR];
-        uint32_t bs[TR];
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
-            big[r] = kNone; bk[r] = 0; bs[r] = 0u;
+            big[r] = kNone; bk[r] = 0;
             if (128 * r + 1 < 64 * TR) { // (slots of this register can have children inside the array)
                 const uint32_t g = (uint32_t)r * 64u + lane, cl = 2u * g + 1u, cr = 2u * g + 2u;
                 const int s0 = 2 * r, s1 = 2 * r + 2 < TR ? 2 * r + 2 : TR - 1;
                 const int kl = fetch(kd, cl & (64u * TR - 1u), s0, s1), kr = fetch(kd, cr & (64u * TR - 1u), s0, s1);
-                const uint32_t sl = fetch(ks, cl & (64u * TR - 1u), s0, s1), sr = fetch(ks, cr & (64u * TR - 1u), s0, s1);
-                const bool hasl = cl < n, right = cr < n && key(kl) <= key(kr); // `hole.get(child) <= hole.get(child + 1)`: the right one
-                big[r] = hasl ? (right ? cr : cl) : kNone;
+                const bool hasl = cl < n, right = cr < n && kl <= kr; // `hole.get(child) <= hole.get(child + 1)`: the right one
                 bk[r] = right ? kr : kl;
-                bs[r] = right ? sr : sl;
+                big[r] = (hasl && bk[r] >= ke) ? (right ? cr : cl) : kNone;
             }
         }
         unsigned long long take[TR];
 #pragma unroll
         for (int r = 0; r < TR; ++r) take[r] = 0ull;
         uint32_t p = 0;
-        for (;;) { // the larger-child path from the root while its nodes stay above e (`e <= parent` ends the closing sift_up)
+        for (;;) { // the larger-child path from the root while its nodes stay above e
             const uint32_t c = at(big, p);
             if (c == kNone) break;
-            if (!(key(at(bk, p)) >= ke)) break;
 #pragma unroll
             for (int r = 0; r < TR; ++r) if ((p >> 6) == (uint32_t)r) take[r] |= 1ull << (p & 63u);
             p = c;
@@ -910,8 +906,10 @@ struct ParHeap {
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             const bool tk = (take[r] >> lane) & 1ull, isp = (uint32_t)r * 64u + lane == p;
-            kd[r] = tk ? bk[r] : (isp ? eb : kd[r]);
-            ks[r] = tk ? bs[r] : (isp ? es : ks[r]);
+            uint32_t bs = 0u;
+            if (128 * r + 1 < 64 * TR) bs = fetch(ks, big[r] & (64u * TR - 1u), 2 * r, 2 * r + 2 < TR ? 2 * r + 2 : TR - 1); // (the slot moves with the key)
+            kd[r] = tk ? bk[r] : (isp ? ke : kd[r]);
+            ks[r] = tk ? bs : (isp ? es : ks[r]);
         }
     }
     // some node of the root-to-slot-K path equals its off-path child (heap full: len == K)
@@ -978,7 +976,7 @@ __device__ __attribute__((noinline)) RegHeap<TR> tie_log_replay(float* heap_d, u
             const int dbits = __builtin_amdgcn_readlane(e_d, (int)j);
             const uint32_t hlen = reg_heap ? HeapOps::uni(ph.len) : lh.len;
             const bool full = hlen == top_k;
-            const int rootb = !full ? 0x7f800000 : (reg_heap ? __builtin_amdgcn_readlane(ph.kd[0], 0) : __float_as_int(heap_d[0]));
+            const int rootb = !full ? 0x7f800000 : (reg_heap ? HeapOps::key(__builtin_amdgcn_readlane(ph.kd[0], 0)) : __float_as_int(heap_d[0]));
             if (lb >= __int_as_float(rootb)) continue;                  // `lower_bound >= distk`: skipped
             if (!finite_f(__int_as_float(dbits))) continue;             // non-finite distance: dropped
             if (full && HeapOps::key(dbits) > HeapOps::key(rootb)) {    // pushed and popped again: the heap is unchanged ...
@@ -988,7 +986,7 @@ __device__ __attribute__((noinline)) RegHeap<TR> tie_log_replay(float* heap_d, u
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)e_s, (int)j);
             ++n_real;
             if (reg_heap) {
-                ph.push(dbits, slot, lane);
+                ph.push(HeapOps::key(dbits), slot, lane);
                 if (ph.len > top_k) ph.pop(lane);
             } else {
                 if (lane == 0) {
@@ -1006,9 +1004,9 @@ __device__ __attribute__((noinline)) RegHeap<TR> tie_log_replay(float* heap_d, u
     if (stats && lane == 0) atomicAdd(stats + 3, (unsigned int)((__builtin_amdgcn_s_memtime() - tt0) >> 6)); // (diagnostic build: slot 3 = ticks / 64)
 #endif
     RegHeap<TR> rh;
-    rh.hd = ph.kd[0]; rh.hs = ph.ks[0]; rh.xd = 0; rh.xs = 0u;
+    rh.hd = HeapOps::key(ph.kd[0]); rh.hs = ph.ks[0]; rh.xd = 0; rh.xs = 0u; // (keys back to distance bits)
 #pragma unroll
-    for (int r = 1; r < TR; ++r) { rh.xd[r] = ph.kd[r]; rh.xs[r] = ph.ks[r]; }
+    for (int r = 1; r < TR; ++r) { rh.xd[r] = HeapOps::key(ph.kd[r]); rh.xs[r] = ph.ks[r]; }
     rh.len = reg_heap ? ph.len : lh.len;
     return rh;
 }

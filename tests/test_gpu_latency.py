@@ -135,3 +135,61 @@ def test_latency_path_degenerate_queries():
     ids, sc, cnt, _ = idx.batch_search_raw(qs[:2], rq.SearchParams(10, 8))
     assert np.array_equal(ids, oids) and np.array_equal(cnt, ocnt)
     idx.close()
+
+
+# ---- tie log of k_scan (round 5): a tied query replays its logged candidates through the BinaryHeap emulation ---------------------------
+@pytest.mark.parametrize("top_k,dim,bits", [(10, 64, 7), (3, 64, 7), (100, 64, 7), (128, 64, 7), (200, 64, 3), (10, 960, 7), (100, 960, 7), (16, 128, 1)])
+def test_tie_log_replay_matches_oracle(top_k, dim, bits):
+    """Duplicated vectors: equal distances inside the top-k, i.e. results that depend on the layout of the reference's BinaryHeap
+    (src/ivf.rs:904-931, :2116-2126).  k_scan (scan_wave = 0) without diagnostics settles them by replaying the tie log through the
+    lane-parallel heap (top_k = 128: the LDS heap; 200: four registers per lane; 960 dimensions: the instantiations at their register
+    limit; 1 bit: no refinement, the estimates are logged): ids, scores and counts equal the oracle's; the same call with the log
+    switched off (the query is scanned again) and with a log too small for the query (overflow: scanned again) give the same bits."""
+    base = make_dataset(900, dim, 4, 5500 + top_k)
+    data = np.concatenate([base, base, base[:400]], axis=0)
+    _, built = build_index(nlist=12, total_bits=bits, data=data, dim=dim)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    idx.set_option("scan_wave", 0)
+    q = np.ascontiguousarray(base[:40])
+    s0 = idx.tie_log_stats()
+    ids, sc, cnt = _compare(built, idx, q, top_k, 8)
+    s1 = idx.tie_log_stats()
+    assert s1["replays"] > s0["replays"] and s1["overflows"] == s0["overflows"], (s0, s1)
+    assert s1["entries"] > s1["heap_ops"] >= s1["replays"]  # (some logged candidates are skipped or pushed-and-popped: no heap operation)
+    idx.set_option("tie_log", 0)
+    a = idx.batch_search_raw(q, rq.SearchParams(top_k, 8))
+    s2 = idx.tie_log_stats()
+    assert s2["replays"] == s1["replays"]
+    idx.set_option("tie_log", 1)
+    idx.set_option("tie_log_cap", 8)
+    b = idx.batch_search_raw(q, rq.SearchParams(top_k, 8))
+    s3 = idx.tie_log_stats()
+    assert s3["overflows"] > s2["overflows"], (s2, s3)
+    idx.set_option("tie_log_cap", 0)
+    for x in (a, b):
+        assert np.array_equal(x[0], ids) and np.array_equal(x[2], cnt) and np.array_equal(x[1].view(np.uint32), sc.view(np.uint32))
+    idx.close()
+
+
+def test_tie_log_seeded_sweep():
+    """Random small indexes with heavy duplication, random top_k / nprobe: the tie log's answer equals the oracle's on every one."""
+    rng = np.random.default_rng(5600)
+    for it in range(12):
+        dim = int(rng.choice([32, 64, 128, 200]))
+        nb = int(rng.integers(200, 600))
+        base = make_dataset(nb, dim, 3, 5601 + it)
+        reps = int(rng.integers(2, 5))
+        data = np.concatenate([base] * reps, axis=0)
+        bits = int(rng.choice([1, 3, 7]))
+        metric = int(rng.integers(0, 2))
+        if metric == 1:
+            data = data / np.linalg.norm(data, axis=1, keepdims=True)
+        nlist = int(rng.integers(4, 14))
+        _, built = build_index(nlist=nlist, total_bits=bits, data=np.ascontiguousarray(data.astype(np.float32)), dim=dim, metric=metric)
+        idx = rq.IvfRabitqIndex.from_built(built)
+        idx.set_option("scan_wave", 0)
+        top_k = int(rng.choice([1, 2, 7, 10, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256]))
+        nprobe = int(rng.integers(1, nlist + 1))
+        q = np.ascontiguousarray(data[rng.integers(0, len(data), 24)].astype(np.float32))
+        _compare(built, idx, q, top_k, nprobe)
+        idx.close()
