@@ -38,7 +38,7 @@ Prints one JSON line (rank 0).  What the objects mean:
   cpu_baseline          the oracle (C restatement of the reference's AVX2/AVX-512 FastScan path) on the host cores: median
                         of 3 passes on the fastest thread count of a short sweep, plus the single-thread figure (how the
                         reference times itself)
-  latency               p50 / p99 of ONE rbq_search_batch call at nq in {1, 8, 64, 256} (page-locked buffers)
+  latency               p50 / p99 of ONE rbq_search_batch call at nq in {1, 4, 8, 64, 256} (page-locked buffers); nq 1 and 64 also through the batch kernels
   self_check            256 queries again with every shortcut off (exact all-pairs ranking, BinaryHeap emulation, no block
                         bound): identical bits — the check that also covers indexes no CPU oracle run can (cfg5)
 """
@@ -696,7 +696,7 @@ def main():
         (examples/recall_qps_sweep.rs:127-138)."""
         lib = rq.index.lib()
         res = {}
-        for nq_ in (1, 8, 64, 256):
+        for nq_ in (1, 4, 8, 64, 256):
             if nq_ > NB * a.batch:
                 continue
             nsets = 16 if nq_ <= 64 else 8
@@ -714,7 +714,20 @@ def main():
             ts = np.array(ts) * 1e6
             res[str(nq_)] = {"p50_us": round(float(np.percentile(ts, 50)), 1), "p99_us": round(float(np.percentile(ts, 99)), 1),
                              "mean_us": round(float(ts.mean()), 1), "queries_per_s_sequential_calls": nq_ / (float(ts.mean()) * 1e-6), "calls": reps}
+            if nq_ in (1, 64):  # the same calls through the batch kernels (k_prep_wave + GEMM): what the latency-first path (latency.hpp) buys
+                idx.set_option("latency_path", 0)
+                for j in range(nsets):
+                    call(j)
+                t2 = []
+                for r in range(reps):
+                    t0 = time.perf_counter()
+                    call(r % nsets)
+                    t2.append(time.perf_counter() - t0)
+                idx.set_option("latency_path", 1)
+                res[str(nq_)]["p50_us_batch_kernels"] = round(float(np.percentile(np.array(t2) * 1e6, 50)), 1)
             free_sets(pin)
+        res["path"] = ("calls of up to 4 queries: k_lat_front (rotation + constants + LUT + the exact score of every list, one launch) + selection + "
+                       "scan; up to 512 queries: the preparation with a workgroup per query; p50_us_batch_kernels = option latency_path = 0")
         res["note"] = ("one caller thread, one call at a time, distinct queries per call, page-locked buffers (rbq_host_alloc); "
                        "includes H2D of the queries, the four kernels and the results written to host memory. Context only: the "
                        "reference publishes sequential single-query numbers on its own hardware "
@@ -1197,6 +1210,7 @@ def main():
                    "host_call_us_per_1024_query_call": ((host_call or {}).get("us_per_call") or {}).get("median"),
                    "latency_p50_us_1_query": ((latency or {}).get("1") or {}).get("p50_us") if isinstance(latency, dict) else None,
                    "latency_p50_us_64_queries": ((latency or {}).get("64") or {}).get("p50_us") if isinstance(latency, dict) else None,
+                   "latency_p50_us_256_queries": ((latency or {}).get("256") or {}).get("p50_us") if isinstance(latency, dict) else None,
                    "value_is": "device-resident rate (queries and results in HBM); host_call_* = ONE rbq_search_batch call per step"},
         "recall_at_10" if a.top_k == 10 else f"recall_at_{a.top_k}": recall,
         "recall_ok": recall_ok,
@@ -1206,6 +1220,7 @@ def main():
         "encoder": encoder,
         "rank_fallbacks": int(idx.rank_fallbacks()),
         "heap_restarts": int(idx.heap_restarts()),
+        "tie_log": idx.tie_log_stats(),  # k_scan (host calls): tied queries that replayed their logged candidates instead of their lists
         "head_exact": dict(zip(("evaluations", "guard_trips"), idx.head_exact_stats())),
         "roofline": roofline,
         "pruned": pruned,

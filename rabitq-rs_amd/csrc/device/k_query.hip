@@ -45,8 +45,8 @@ hipError_t launch_lat_front(const PrepParams& p, const RankParams& r, int device
     P.queries = p.queries; P.nq = p.nq; P.dim = p.dim; P.D = p.D; P.Dc = p.Dc; P.rotator = p.rotator; P.rot_blob = p.rot_blob;
     P.trunc = p.trunc; P.fac = p.fac; P.ex_bits = p.ex_bits; P.rot = p.rot; P.lut = p.lut; P.consts = p.consts;
     P.cent = r.cent; P.nlist = r.nlist; P.metric = r.metric; P.scores = r.scores;
-    P.rot_hi = p.rot_hi; P.rot_lo = p.rot_lo; P.scorers = r.scores ? 1u : 0u;
-    const dim3 grid(P.scorers ? (r.nlist + kLatLists - 1) / kLatLists + 1 : 1u, p.nq);
+    P.rot_hi = p.rot_hi; P.rot_lo = p.rot_lo; P.scorers = r.scores ? (r.nlist + kLatLists - 1) / kLatLists : 0u;
+    const dim3 grid(lat_front_grid(P.scorers, p.nq));
     const size_t lds = (size_t)p.D * 4 * 2 + p.D / 2;
     if (probe_stage(0, reinterpret_cast<const void*>(&k_lat_front), grid, kThreads, lds)) return hipSuccess;
     hipError_t e = attr.ensure(reinterpret_cast<const void*>(&k_lat_front), lds, device);

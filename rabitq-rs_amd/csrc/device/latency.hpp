@@ -7,7 +7,7 @@
 // instructions each, one after the other: the preparation alone is 13 us of ONE wave (rotation, two 960-step serial sums, 2 x 240
 // IEEE divisions), the MFMA GEMM + radix shortlist for 4096 x 960 MACs is pure overhead (tools/lat_trace.py).  Here the
 // query's work is spread over the chip instead:
-//   grid = (ceil(n_lists / 32) + 1, nq) workgroups of 256 threads.  EVERY workgroup rotates its query itself (wave 0, ~2 us: cheaper
+//   (ceil(n_lists / 32) + 1) x nq workgroups of 256 threads (lat_front_grid).  EVERY workgroup rotates its query itself (wave 0, ~2 us: cheaper
 //   than a launch boundary), then
 //   * workgroups 0 .. G-1 score 32 lists each, eight lanes per list straight from global memory (64 loads in flight per lane), and
 //     write the EXACT canonical score into the row the probe selection reads — the selection's rigorous |A - canonical| <= eps
@@ -38,9 +38,15 @@ struct LatFrontParams {
     int metric;
     float* scores;        // [nq][nlist] exact canonical scores (L2: squared distance; IP: dot)
     uint16_t *rot_hi, *rot_lo; // null, or the split-bf16 image of the rotated query (the ranking GEMM's operand: `scorers` = 0)
-    uint32_t scorers;     // 1: grid.x = ceil(nlist / 32) + 1; 0: grid.x = 1 — preparation only, the ranking GEMM follows (medium batches:
-                          // a workgroup per query finishes a query's preparation in ~2/3 of the time one wave of k_prep_wave needs)
+    uint32_t scorers;     // G = ceil(nlist / 32) scoring workgroups per query, or 0: preparation only, the ranking GEMM follows (medium
+                          // batches: a workgroup per query finishes a query's preparation in ~2/3 of the time one wave of k_prep_wave needs)
 };
+// Workgroup -> (query, role) mapping.  Consecutive workgroup ids go to consecutive XCDs (8 of them, each with its own L2), so with
+// several queries the id is cut as  id = (slot * 8 + xcd),  slot = (role block * nq + query):  the nq workgroups that score the SAME 32
+// lists for the nq queries land on one XCD, back to back — the centroid rows come from HBM once and from that L2 nq - 1 times.
+__host__ __device__ inline uint32_t lat_front_grid(uint32_t scorers, uint32_t nq) {
+    return scorers ? ((scorers + 1u + 7u) / 8u) * 8u * nq : nq;
+}
 
 // dynamic LDS: x[D] f32 (the rotated query) | x2[D] f32 (its squares: the |q|^2 chain) | 4*D/8 flip bytes
 __global__ __launch_bounds__(kThreads) void k_lat_front(const LatFrontParams P) {
@@ -49,7 +55,14 @@ __global__ __launch_bounds__(kThreads) void k_lat_front(const LatFrontParams P) 
     __shared__ unsigned int s_amin, s_amax;
     __shared__ float s_sum, s_n2, s_sp, s_sn;
     const uint32_t D = P.D, Dc = P.Dc, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t q = blockIdx.y, g = blockIdx.x, G = gridDim.x - 1u;
+    const uint32_t G = P.scorers;
+    uint32_t q = blockIdx.x, g = 0;
+    if (G) {
+        const uint32_t slot = blockIdx.x >> 3;
+        q = slot % P.nq;
+        g = (slot / P.nq) * 8u + (blockIdx.x & 7u);
+        if (g > G) return; // (padding of the role count to a multiple of 8)
+    }
     float* x = sm;
     float* x2 = sm + D;
     uint8_t* flips = reinterpret_cast<uint8_t*>(sm + (size_t)2 * D);

@@ -230,7 +230,7 @@ constexpr uint64_t kHostWaveMinQueries = 4096;
 // Latency-first front (latency.hpp): one launch rotates the query, builds its LUT and scores EVERY list exactly, spread over
 // n_lists / 32 workgroups per query.  It re-reads the centroid table once per query, so it serves calls of a few queries only
 // (every query's pass over the table must stay a few microseconds: n_lists x D x 4 bytes x nq within kLatMaxBytes).
-constexpr uint64_t kLatMaxQueries = 8;
+constexpr uint64_t kLatMaxQueries = 4; // (measured, GIST-1M shape: 1 / 2 / 4 queries per call -12 / -10 / -12 us against prep + GEMM; 8: no gain)
 constexpr uint64_t kLatMaxBytes = 96ull << 20;
 constexpr uint64_t kPrepWgMaxQueries = 512; // up to here the preparation runs one WORKGROUP per query (latency.hpp without the scorers)
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r4_records.sh : the round-5 bench records committed under profiles/r5/ (GPU box; writes gpurun_out/final_r5/*.json).
+# tools/r5_records.sh : the round-5 bench records committed under profiles/r5/ (GPU box; writes gpurun_out/final_r5/*.json).
 # Per-configuration records carry cpu_baseline and the oracle id check (round-3 VERDICT item 6).
 cd "$(dirname "$0")/.."
 out=gpurun_out/final_r5; rm -rf $out; mkdir -p $out
