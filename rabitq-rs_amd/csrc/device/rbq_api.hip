@@ -1121,10 +1121,13 @@ int scan_stage(Replica* ix, Workspace* w, uint64_t nq, uint32_t probe_stride, ui
     P.wave_kernel = (ix->scan_wave == 1 || (ix->scan_wave == 2 && nq >= kScanWaveMinQueries && !ix->no_block_bound && !w->latency_first)) ? 1u : 0u;
     // tie log (k_scan, no diagnostics, top-k in registers): a tied query replays its logged candidates instead of its lists
     P.tie_log = nullptr; P.tie_log_cap = 0;
-    if (ix->tie_log && !P.wave_kernel && !d_diag && !mstg && top_k >= 1 && top_k <= kTopKRegMax && !ix->exact_heap) {
-        const uint32_t cap = ix->tie_log_cap ? ix->tie_log_cap : (top_k < 64u ? 4096u : 16384u); // (option tie_log_cap: tests of the overflow path)
-        if ((uint64_t)nq * cap * 12u <= (1ull << 30) && w->tie_log.ensure((size_t)nq * cap * 12u) == RBQ_OK) {
-            P.tie_log = (uint32_t*)w->tie_log.p; P.tie_log_cap = cap;
+    if (ix->tie_log && !P.wave_kernel && !d_diag && !mstg && top_k >= 1 && top_k <= kTopKRegMax && !ix->exact_heap && !stage_probes()) {
+        // entries per query: ~80 candidates are refined per query at top_k = 10 and ~400 at top_k = 100 on the bench data; a query that
+        // logs more than the capacity is scanned again, as before (option tie_log_cap: tests of that path)
+        const uint32_t cap = ix->tie_log_cap ? ix->tie_log_cap : (top_k < 64u ? 2048u : 8192u);
+        if ((uint64_t)nq * cap * 12u <= (1ull << 30)) {
+            if (w->tie_log.ensure((size_t)nq * cap * 12u) == RBQ_OK) { P.tie_log = (uint32_t*)w->tie_log.p; P.tie_log_cap = cap; }
+            else { (void)hipGetLastError(); g_err.clear(); } // (no memory for the log: the call is served without it)
         }
     }
     P.heap_ws = nullptr;
