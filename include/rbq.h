@@ -287,6 +287,12 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *                        neither scored exactly nor streamed; their sizes still count in skipped_by_lower_bound)
  *   "profile_counters" 0 an open profile (rbq_profile_begin) keeps its stage timings but not the traffic counters (default 1; the
  *                        counters cost a pipelined caller 2-3 %: bench.py times without them and counts in a pass of its own)
+ *   "latency_path" 0     small calls through the batch kernels (default 1: calls of up to 4 queries rotate the query, build its LUT and
+ *                        score every list exactly in ONE launch; batches up to 512 queries are prepared by a workgroup per query)
+ *   "tie_log" 0          a query with equal distances in its top-k is scanned again with the BinaryHeap emulation (default 1: k_scan
+ *                        logs the candidates it refines — 12 B each, up to 8192 per query in the calling stream's workspace — and the
+ *                        tied query replays the log; rbq_debug_tie_log_stats)
+ *   "scan_wave" 0/1/2    which scan kernel serves a call
  * and two that are not result-neutral:
  *   "rerank" 0/1         the optional full-precision rerank (needs rbq_index_set_rerank_vectors)
  *   "debug_replica" r    which replica rbq_debug_copy_index / rbq_debug_copy_workspace read */

@@ -1492,7 +1492,7 @@ Replica* replica_of_pointer(rbq_index* h, const void* dptr) {
 
 extern "C" {
 
-uint32_t rbq_abi_version(void) { return (2u << 16) | 0u; }
+uint32_t rbq_abi_version(void) { return (2u << 16) | 1u; } // (minor 1: rbq_debug_tie_log_stats; options latency_path, tie_log)
 
 const char* rbq_strerror(int code) {
     switch (code) {
