@@ -993,17 +993,28 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
         uint32_t lk[KL];
 #pragma unroll
         for (int u = 0; u < KL; ++u) lk[u] = 0xffffffffu;
-        for (uint32_t i = tid; i < nlist; i += kThreads) {
-            const float v = grow[i];
-            bad_load |= !finite_f(v);
-            const uint32_t key = okey(v);
-            if (key < lk[KL - 1]) { // insertion into the ascending register list
-                lk[KL - 1] = key;
+        // (eight loads in flight per thread: left as one load per iteration, every iteration exposed a global round trip in front of
+        // its compare — 256 dependent trips per thread and pass at 65 536 lists; round 5)
+        constexpr int KU = 8;
+        for (uint32_t i0 = tid; i0 < nlist; i0 += kThreads * KU) {
+            float vv[KU];
 #pragma unroll
-                for (int u = KL - 1; u > 0; --u) {
-                    const uint32_t a = lk[u - 1], b = lk[u];
-                    lk[u - 1] = a < b ? a : b;
-                    lk[u] = a < b ? b : a;
+            for (int w = 0; w < KU; ++w) { const uint32_t i = i0 + (uint32_t)w * kThreads; vv[w] = i < nlist ? grow[i] : 0.0f; }
+#pragma unroll
+            for (int w = 0; w < KU; ++w) {
+                if (i0 + (uint32_t)w * kThreads < nlist) {
+                    const float v = vv[w];
+                    bad_load |= !finite_f(v);
+                    const uint32_t key = okey(v);
+                    if (key < lk[KL - 1]) { // insertion into the ascending register list
+                        lk[KL - 1] = key;
+#pragma unroll
+                        for (int u = KL - 1; u > 0; --u) {
+                            const uint32_t a = lk[u - 1], b = lk[u];
+                            lk[u - 1] = a < b ? a : b;
+                            lk[u] = a < b ? b : a;
+                        }
+                    }
                 }
             }
         }
@@ -1015,11 +1026,18 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
         if (tid == 0) s_nc = 0;
         __syncthreads();
         if (cutB != 0xffffffffu && s_bad == 0) {
-            for (uint32_t i = tid; i < nlist; i += kThreads) {
-                const uint32_t key = okey(grow[i]);
-                if (key <= cutB) {
-                    const uint32_t pp = atomicAdd(&s_nc, 1u);
-                    if (pp < G.cand_cap) cand[pp] = ((uint64_t)key << 32) | i;
+            for (uint32_t i0 = tid; i0 < nlist; i0 += kThreads * KU) {
+                float vv[KU];
+#pragma unroll
+                for (int w = 0; w < KU; ++w) { const uint32_t i = i0 + (uint32_t)w * kThreads; vv[w] = i < nlist ? grow[i] : 0.0f; }
+#pragma unroll
+                for (int w = 0; w < KU; ++w) {
+                    const uint32_t i = i0 + (uint32_t)w * kThreads;
+                    const uint32_t key = okey(vv[w]);
+                    if (i < nlist && key <= cutB) {
+                        const uint32_t pp = atomicAdd(&s_nc, 1u);
+                        if (pp < G.cand_cap) cand[pp] = ((uint64_t)key << 32) | i;
+                    }
                 }
             }
             __syncthreads();
