@@ -128,6 +128,36 @@ __device__ __forceinline__ float ex_dot_units(const uint8_t* __restrict__ ex, co
     }
     return sacc;
 }
+// Same arithmetic with all units of a vector resident in registers (nunits <= kExRegUnits), so that the units
+// of the NEXT survivor can be in flight while this one is evaluated (heavy tiles: hundreds of survivors).
+constexpr int kExRegUnits = 4;
+__device__ __forceinline__ void ex_load_all(uint4 (&u)[kExRegUnits], const uint8_t* __restrict__ ex, uint32_t gl, uint32_t nunits) {
+    const uint4* p = reinterpret_cast<const uint4*>(ex) + gl;
+#pragma unroll
+    for (int j = 0; j < kExRegUnits; ++j) u[j] = p[((uint32_t)j < nunits ? j : 0) * 16];
+}
+template <int EX>
+__device__ __forceinline__ float ex_dot_all(const uint4 (&u)[kExRegUnits], const float* sq, uint32_t gl, uint32_t nunits) {
+    constexpr int CPU = 128 / EX;
+    constexpr uint32_t mask = (1u << EX) - 1u;
+    float sacc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kExRegUnits; ++j) {
+        if ((uint32_t)j < nunits) { // wave-uniform
+            const uint32_t w[5] = {u[j].x, u[j].y, u[j].z, u[j].w, 0u};
+            const float* qj = sq + j * CPU * 16 + gl;
+#pragma unroll
+            for (int k = 0; k < CPU; ++k) {
+                const int bit = k * EX, idx = bit >> 5, sh = bit & 31;
+                uint32_t code;
+                if (sh + EX <= 32) code = (w[idx] >> sh) & mask;
+                else code = ((w[idx] >> sh) | (w[idx + 1] << (32 - sh))) & mask;
+                sacc = fmaf((float)code, qj[16 * k], sacc);
+            }
+        }
+    }
+    return sacc;
+}
 __device__ __forceinline__ float group16_reduce(float sacc) { // _mm512_reduce_add_ps halving tree
     sacc = sacc + __shfl_xor(sacc, 8, 16);
     sacc = sacc + __shfl_xor(sacc, 4, 16);

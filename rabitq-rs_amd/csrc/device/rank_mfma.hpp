@@ -616,6 +616,12 @@ __device__ __forceinline__ void sort_keys(uint64_t* keys, uint32_t n, uint32_t c
 }
 
 
+#ifndef RBQ_HX_EX_ALL
+#define RBQ_HX_EX_ALL 0 // (1: the refined head vectors with every code unit in flight — 110 registers, four waves per SIMD: -3 % queries/s, measured)
+#endif
+#ifndef RBQ_HX_GRANULES
+#define RBQ_HX_GRANULES 4 // code granules of a head vector requested before its first lookup (head_exact_bound)
+#endif
 // ---- exact head evaluation (k_select_mfma step 3b) -----------------------------------------------------------------------
 // LDS scratch layout (shares the region of the LDS scorer's rows): lut[4 Dc] u8 | sq[ex_qlen] f32 | est[nv] | lb[nv] | ip[nv] | U[nv]
 __host__ __device__ inline size_t hx_scratch_bytes(uint32_t D, uint32_t Dc, uint32_t ex_bits, uint32_t nv) {
@@ -683,18 +689,27 @@ __device__ __forceinline__ float head_exact_bound(const SelectParams& P, const S
         const uint8_t* blk = P.blocks + (size_t)(gb + b) * stride;
         const uint32_t G16 = Dc >> 7;
         const uint4* cp = reinterpret_cast<const uint4*>(blk) + l32;
-        uint32_t acc = 0;
-        for (uint32_t g = 0; g < G16; ++g) {
-            const uint4 x = cp[g * 32];
-            acc += hx_look8(x.x, lutL + g * 512) + hx_look8(x.y, lutL + g * 512 + 128) + hx_look8(x.z, lutL + g * 512 + 256) +
-                   hx_look8(x.w, lutL + g * 512 + 384);
-        }
-        if (Dc & 64u) {
-            const uint2 y = *(reinterpret_cast<const uint2*>(blk + G16 * 512) + l32);
-            acc += hx_look8(y.x, lutL + G16 * 512) + hx_look8(y.y, lutL + G16 * 512 + 128);
-        }
+        // the factor rows and RBQ_HX_GRANULES code granules at a time are requested before the first lookup: the loop
+        // as hipcc left it waited for every granule in front of its lookups — D/128 dependent global round trips per head evaluation
         const float* fac = reinterpret_cast<const float*>(blk + (size_t)Dc * 4);
         const float f_add = fac[l32], f_rescale = fac[32 + l32], f_error = fac[64 + l32];
+        uint2 ytail = make_uint2(0u, 0u);
+        if (Dc & 64u) ytail = *(reinterpret_cast<const uint2*>(blk + G16 * 512) + l32);
+        uint32_t acc = 0;
+        constexpr int KG = RBQ_HX_GRANULES; // code granules in flight (4: 16 registers, the kernel keeps five waves per SIMD)
+        for (uint32_t g0 = 0; g0 < G16; g0 += KG) {
+            uint4 xx[KG];
+#pragma unroll
+            for (int u = 0; u < KG; ++u) xx[u] = g0 + (uint32_t)u < G16 ? cp[(g0 + u) * 32] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < KG; ++u) {
+                if (g0 + (uint32_t)u < G16) {
+                    const uint8_t* lg = lutL + (g0 + u) * 512;
+                    acc += hx_look8(xx[u].x, lg) + hx_look8(xx[u].y, lg + 128) + hx_look8(xx[u].z, lg + 256) + hx_look8(xx[u].w, lg + 384);
+                }
+            }
+        }
+        if (Dc & 64u) acc += hx_look8(ytail.x, lutL + G16 * 512) + hx_look8(ytail.y, lutL + G16 * 512 + 128);
         const float ip = fmaf(qc.delta, (float)(acc & 0xffffu), qc.sum_vl);
         const float tt = ip + qc.k1x;
         const float rs = f_rescale * tt;
@@ -749,10 +764,15 @@ __device__ __forceinline__ float head_exact_bound(const SelectParams& P, const S
             if (v >= nv) { if (gl == 0 && P.fallback_count) atomicAdd(P.fallback_count + 2, 1u); v = 0; } // (guard: cannot happen; never read out of the list)
             const uint32_t slot = (gb + (v >> 5)) * 32u + (v & 31u);
             const uint8_t* ex = P.ex_codes + (size_t)slot * exb;
-            float sacc = ex_bits == 6 ? ex_dot_units<6>(ex, sq, gl, nunits) : ex_dot_units<2>(ex, sq, gl, nunits);
+            const float fa = P.f_add_ex[slot], fr = P.f_rescale_ex[slot]; // (requested with the code units)
+            float sacc;
+            if (RBQ_HX_EX_ALL && nunits <= (uint32_t)kExRegUnits) { // every unit in flight before the first is decoded (same arithmetic: ex_dot_all)
+                uint4 uu[kExRegUnits];
+                ex_load_all(uu, ex, gl, nunits);
+                sacc = ex_bits == 6 ? ex_dot_all<6>(uu, sq, gl, nunits) : ex_dot_all<2>(uu, sq, gl, nunits);
+            } else sacc = ex_bits == 6 ? ex_dot_units<6>(ex, sq, gl, nunits) : ex_dot_units<2>(ex, sq, gl, nunits);
             sacc = group16_reduce(sacc);
             if (gl == 0) {
-                const float fa = P.f_add_ex[slot], fr = P.f_rescale_ex[slot];
                 float tt2 = qc.scale * vIp[v];
                 const float t0 = tt2;
                 tt2 = tt2 + sacc;
