@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void k_lat_front(const LatFrontParams P) 
 #endif
     const bool wave_fht = P.rotator == 1 && trunc >= 64 && trunc <= 2048;
     if (P.rotator == 1) {
-        for (uint32_t i = tid; i < D / 2; i += kThreads) flips[i] = P.rot_blob[i];
+        for (uint32_t i = tid; i < D / 8; i += kThreads) reinterpret_cast<uint32_t*>(flips)[i] = reinterpret_cast<const uint32_t*>(P.rot_blob)[i]; // (4 D / 8 flip bytes as dwords: one trip)
         if (wave == 0 && wave_fht) fhtkac_initial_load(x, qin, P.dim, D, trunc, P.rot_blob, lane);
         __syncthreads();
     }

@@ -266,9 +266,23 @@ __device__ __forceinline__ void fht_wave(float* part, uint32_t lane, float fac, 
 // it BEFORE the barrier behind the copy of the flip bits into LDS: `flips0` may be the global table.
 __device__ __forceinline__ void fhtkac_initial_load(float* x, const float* __restrict__ qin, uint32_t dim, uint32_t D, uint32_t trunc,
                                                     const uint8_t* __restrict__ flips0, uint32_t lane) {
-    for (uint32_t i = lane; i < D; i += 64) {
-        const float v = i < dim ? qin[i] : 0.0f;
-        x[i] = (trunc != D && ((flips0[i >> 3] >> (i & 7u)) & 1u)) ? -v : v;
+    // eight elements per lane are REQUESTED before the first is written to LDS: as a plain loop hipcc waited for every load in front
+    // of its ds_write — D / 64 dependent global round trips (15 at D = 960) at the head of every query's preparation (round 5)
+    constexpr int KU = 8;
+    for (uint32_t i0 = lane; i0 < D; i0 += 64 * KU) {
+        float v[KU];
+        uint32_t f[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const uint32_t i = i0 + 64u * u;
+            v[u] = i < dim ? qin[i] : 0.0f; // (dim <= D)
+            f[u] = (trunc != D && i < D) ? (uint32_t)flips0[i >> 3] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const uint32_t i = i0 + 64u * u;
+            if (i < D) x[i] = ((f[u] >> (i & 7u)) & 1u) ? -v[u] : v[u];
+        }
     }
 }
 template <int EPL>
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(kThreads) void k_prep_wave(const float* __restrict_
     const float* qin = queries + (size_t)q * dim;
     const bool wave_fht = rotator == 1 && trunc >= 64 && trunc <= 2048; // (else the generic LDS butterflies)
     if (rotator == 1) {
-        for (uint32_t i = threadIdx.x; i < D / 2; i += kThreads) flips[i] = rot_blob[i];
+        for (uint32_t i = threadIdx.x; i < D / 8; i += kThreads) reinterpret_cast<uint32_t*>(flips)[i] = reinterpret_cast<const uint32_t*>(rot_blob)[i]; // (4 D / 8 flip bytes as dwords: one trip)
         // the query is requested together with the flip table (round 0's flips straight from the global table): one
         // round trip in front of the barrier instead of two around it
         if (q < nq && wave_fht) fhtkac_initial_load(x, qin, dim, D, trunc, rot_blob, lane);

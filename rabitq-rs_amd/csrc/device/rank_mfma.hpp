@@ -418,10 +418,27 @@ __device__ __forceinline__ void canon_score_staged(uint64_t* keys, const float* 
     const uint32_t Dp = D + 8u, Dmain = D & ~7u, nv4 = D >> 2; // (+8 floats: the 8 lanes of consecutive rows hit distinct banks)
     for (uint32_t base = 0; base < m; base += RB) {
         const uint32_t nr = m - base < RB ? m - base : RB;
-        for (uint32_t x = tid; x < nr * nv4; x += kThreads) {
-            const uint32_t r = x / nv4, j4 = x - r * nv4;
-            const uint32_t cid = (uint32_t)keys[idx_of(base + r)];
-            *reinterpret_cast<float4*>(rows + (size_t)r * Dp + 4 * j4) = *reinterpret_cast<const float4*>(cent + (size_t)cid * D + 4 * j4);
+        // (four 16-byte loads per thread in flight: as a plain copy loop every iteration waited for its load in front of its ds_write)
+        for (uint32_t x0 = tid; x0 < nr * nv4; x0 += 4 * kThreads) {
+            float4 t4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t x = x0 + (uint32_t)u * kThreads;
+                t4[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (x < nr * nv4) {
+                    const uint32_t r = x / nv4, j4 = x - r * nv4;
+                    const uint32_t cid = (uint32_t)keys[idx_of(base + r)];
+                    t4[u] = *reinterpret_cast<const float4*>(cent + (size_t)cid * D + 4 * j4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t x = x0 + (uint32_t)u * kThreads;
+                if (x < nr * nv4) {
+                    const uint32_t r = x / nv4, j4 = x - r * nv4;
+                    *reinterpret_cast<float4*>(rows + (size_t)r * Dp + 4 * j4) = t4[u];
+                }
+            }
         }
         __syncthreads();
         if (tid < nr * 8u) {
@@ -916,7 +933,15 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
         }
     };
 
-    for (uint32_t i = tid; i < D; i += kThreads) qrot[i] = P.rot[(size_t)q * D + i];
+    { // (the rotated query: every load of a thread in flight before its first LDS store)
+        float qv[4];
+        for (uint32_t i0 = tid; i0 < D; i0 += 4 * kThreads) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qv[u] = i0 + (uint32_t)u * kThreads < D ? P.rot[(size_t)q * D + i0 + (uint32_t)u * kThreads] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + (uint32_t)u * kThreads < D) qrot[i0 + (uint32_t)u * kThreads] = qv[u];
+        }
+    }
     if (tid == 0) { s_k = nprobe - 1; s_cnt = 0; s_nvec = 0; s_bad = 0; }
     __syncthreads();
 

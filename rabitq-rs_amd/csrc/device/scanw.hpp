@@ -127,13 +127,29 @@ __global__ __launch_bounds__(64, (TR == 1 ? RBQ_SCANW_WAVES1 : RBQ_SCANW_WAVES))
     const uint32_t nunits = ex_w4(D, ex_bits);
 
     {
+        // LUT and rotated query into LDS: four 16-byte loads per lane in flight, LUT and query together (as two plain loops every
+        // iteration waited for its load in front of its ds_write: 8 dependent round trips at D = 960 before the first stream entry)
         const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
         uint4* dst = reinterpret_cast<uint4*>(s_lut);
-        for (uint32_t i = lane; i < Dc / 4; i += 64) dst[i] = src[i];
-        if (ex_bits) {
-            const float4* rs = reinterpret_cast<const float4*>(P.rot + (size_t)q * D);
-            float4* rd = reinterpret_cast<float4*>(s_q);
-            for (uint32_t i = lane; i < qlen / 4; i += 64) rd[i] = i < D / 4 ? rs[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4* rs = reinterpret_cast<const float4*>(P.rot + (size_t)q * D);
+        float4* rd = reinterpret_cast<float4*>(s_q);
+        const uint32_t nl = Dc / 4, nr = ex_bits ? qlen / 4 : 0u;
+        constexpr int KU = 4;
+        for (uint32_t i0 = lane; i0 < nl || i0 < nr; i0 += 64 * KU) {
+            uint4 a[KU];
+            float4 b[KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const uint32_t i = i0 + 64u * u;
+                a[u] = i < nl ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+                b[u] = (i < nr && i < D / 4) ? rs[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const uint32_t i = i0 + 64u * u;
+                if (i < nl) dst[i] = a[u];
+                if (i < nr) rd[i] = b[u];
+            }
         }
     }
     const QueryConsts qc = P.consts[q];
