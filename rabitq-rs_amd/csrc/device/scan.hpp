@@ -1054,7 +1054,17 @@ __global__ __launch_bounds__(kScanThreads, ((TR == 1 && scan_nb((uint32_t)DT) ==
         const uint4* src = reinterpret_cast<const uint4*>(P.lut + (size_t)q * Dc * 4);
         uint4* dst = reinterpret_cast<uint4*>(s_lut);
         for (uint32_t i = tid; i < Dc / 4; i += kScanThreads) dst[i] = src[i];
-        for (uint32_t i = tid; i < qlen; i += kScanThreads) s_q[i] = i < D ? P.rot[(size_t)q * D + i] : 0.0f;
+        // (the rotated query as 16-byte loads, all of a thread's in flight before its first LDS store: the plain dword loop waited for
+        // every load in front of its ds_write — four dependent round trips at D = 960 before the first fill step)
+        const float4* rs = reinterpret_cast<const float4*>(P.rot + (size_t)q * D); // (D % 4 == 0: padded_dim is a multiple of 64)
+        float4* rd = reinterpret_cast<float4*>(s_q);
+        for (uint32_t i0 = tid; i0 < qlen / 4; i0 += 2 * kScanThreads) {
+            float4 b[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const uint32_t i = i0 + (uint32_t)u * kScanThreads; b[u] = (i < qlen / 4 && i < D / 4) ? rs[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const uint32_t i = i0 + (uint32_t)u * kScanThreads; if (i < qlen / 4) rd[i] = b[u]; }
+        }
         if (tid == 0) { s_T = INFINITY; *s_nskip = 0; s_len = 0; s_restart = 0; s_misc[5] = 0; s_misc[6] = 0; s_misc[7] = 0; }
     }
     // the replay wave is the serial part of every tile: let it issue ahead of the (many) scanner waves it shares
