@@ -251,6 +251,8 @@ struct Replica {
     bool raw_borrowed = false;
     bool rerank = false;
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
+    uint32_t host_zero_copy_min = 5;  // option host_zero_copy_min: smallest call whose queries are read in place (up to 4 queries take the
+                                      // latency-first front: a hundred workgroups per query would each read it over PCIe)
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
     bool host_stage_helpers = true; // rbq_search_batch: pageable queries of a call's later sub-batches are staged by helper threads
     std::unique_ptr<StageHelpers> stagers; // (created on the first pageable call, under `mu`; published only when all its threads run)
@@ -1320,7 +1322,9 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     // 2048 per call 445 -> 457 and from 4096 the copy engine clearly beats the waves' own PCIe reads: 678 -> 778 us — hence the window)
     // (pageable queries, read from the lane's pinned staging buffer: 1024 per call 381 -> 373 us, but 2048 per call 524 -> 591 us:
     // there the staged DMA pieces overlap the host copy better than one big copy followed by in-place reads — window <= 1024)
-    const bool zero_copy = ix->host_zero_copy && nq >= 32 && nq <= (in_pinned ? 1536u : 1024u);
+    // (round 5: the preparation kernels now request a query's elements eight at a time instead of one per round trip — 15 PCIe round
+    // trips per query at D = 960 became 2 — and the window opens at 5 queries: 8 per call 149 -> 142 us, 16: 156 -> 149, 24: 161 -> 153)
+    const bool zero_copy = ix->host_zero_copy && nq >= ix->host_zero_copy_min && nq <= (in_pinned ? 1536u : 1024u);
     const float* c_queries = nullptr;
     if (zero_copy && in_pinned && hipHostGetDevicePointer((void**)&c_queries, const_cast<float*>(queries), 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -1993,6 +1997,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
         else if (!std::strcmp(name, "lazy_filter")) ix->lazy_filter = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
+        else if (!std::strcmp(name, "host_zero_copy_min")) ix->host_zero_copy_min = value > 0 ? (uint32_t)value : 1u;
         else if (!std::strcmp(name, "host_stage_helpers")) ix->host_stage_helpers = value != 0;
         else if (!std::strcmp(name, "rerank")) {
             if (value && !ix->raw.p) return fail(RBQ_INVALID_CONFIG, "no raw vectors attached (rbq_index_set_rerank_vectors)");
