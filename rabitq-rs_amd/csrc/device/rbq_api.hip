@@ -251,6 +251,7 @@ struct Replica {
     bool raw_borrowed = false;
     bool rerank = false;
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
+    int host_taper = 0;               // option host_taper: weights of a call's sub-batches (rbq_host_logic.hpp; A/B runs)
     uint32_t host_zero_copy_min = 5;  // option host_zero_copy_min: smallest call whose queries are read in place (up to 4 queries take the
                                       // latency-first front: a hundred workgroups per query would each read it over PCIe)
     bool host_zero_copy = true; // rbq_search_batch: k_prep reads the queries from page-locked host memory in place (no H2D copy command)
@@ -1301,7 +1302,7 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
     auto tick = [&](clk::time_point& t0, double& acc) { if (trace) { const auto t1 = clk::now(); acc += std::chrono::duration<double, std::micro>(t1 - t0).count(); t0 = t1; } };
     clk::time_point tp = clk::now();
     // sub-batches shrink towards the end of the call (rbq_host_logic.hpp): the last one's kernel chain is what the caller waits for
-    const std::vector<std::pair<uint64_t, uint64_t>> plan = rbq_host::subbatch_plan(nq, ix->host_subbatch);
+    const std::vector<std::pair<uint64_t, uint64_t>> plan = rbq_host::subbatch_plan(nq, ix->host_subbatch, ix->host_taper);
     const uint64_t nsub = plan.size();
     const uint32_t nlanes = (uint32_t)std::min<uint64_t>(nsub, ix->host_lanes ? ix->host_lanes : 6u);
     const bool in_pinned = is_pinned_host_range(queries, nq * query_dim * 4);
@@ -1997,6 +1998,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "head_exact")) ix->head_exact = value != 0;
         else if (!std::strcmp(name, "lazy_filter")) ix->lazy_filter = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
+        else if (!std::strcmp(name, "host_taper")) ix->host_taper = value;
         else if (!std::strcmp(name, "host_zero_copy_min")) ix->host_zero_copy_min = value > 0 ? (uint32_t)value : 1u;
         else if (!std::strcmp(name, "host_stage_helpers")) ix->host_stage_helpers = value != 0;
         else if (!std::strcmp(name, "rerank")) {

@@ -172,7 +172,7 @@ inline void shard_range(uint64_t r, uint64_t R, uint64_t nq, uint64_t* q0, uint6
 //                       measured slower there (4096 per call: 828 against 688 us — the chip is saturated, smaller kernels only
 //                       add launches)
 // `forced` (diagnostic option host_subbatch) gives equal sub-batches of that size.
-inline std::vector<std::pair<uint64_t, uint64_t>> subbatch_plan(uint64_t nq, uint64_t forced) {
+inline std::vector<std::pair<uint64_t, uint64_t>> subbatch_plan(uint64_t nq, uint64_t forced, int taper_kind = 0) {
     std::vector<std::pair<uint64_t, uint64_t>> plan;
     if (nq == 0) return plan;
     if (forced) {
@@ -192,7 +192,14 @@ inline std::vector<std::pair<uint64_t, uint64_t>> subbatch_plan(uint64_t nq, uin
         }
     };
     if (nq < 256) { plan.emplace_back(0, nq); return plan; }
-    if (nq <= 2048) { taper(0, nq, {4, 3, 2, 1}); return plan; }
+    if (nq <= 2048) { // (taper_kind: option host_taper — A/B of the weights)
+        if (taper_kind == 1) taper(0, nq, {1, 1, 1, 1});
+        else if (taper_kind == 2) taper(0, nq, {3, 3, 2, 2});
+        else if (taper_kind == 3) taper(0, nq, {4, 4, 3, 2});
+        else if (taper_kind == 4) taper(0, nq, {2, 2, 2, 1});
+        else taper(0, nq, {4, 3, 2, 1});
+        return plan;
+    }
     for (uint64_t q0 = 0; q0 < nq; q0 += 1024) plan.emplace_back(q0, std::min<uint64_t>(1024, nq - q0));
     return plan;
 }
