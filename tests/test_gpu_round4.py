@@ -237,7 +237,7 @@ def test_host_entry_paths_give_identical_results(zero_copy, helpers):
     allowed = np.arange(0, 20000, 3)
     words = np.zeros((20000 + 31) // 32, np.uint32)
     np.bitwise_or.at(words, allowed >> 5, (np.uint32(1) << (allowed & 31).astype(np.uint32)))
-    for nq in (1, 31, 32, 33, 255, 256, 257, 1000, 2048, 2049, 2600):
+    for nq in (1, 4, 5, 6, 31, 32, 33, 255, 256, 257, 512, 513, 1000, 2048, 2049, 2600):  # (4 | 5: latency-first front | in-place query reads; 512 | 513: workgroup | wave per query in the preparation)
         q = make_dataset(nq, 128, 24, 4700 + nq)
         qd = torch.from_numpy(q).to(dev)
         d_i = torch.empty(nq, top_k, dtype=torch.int64, device=dev)
