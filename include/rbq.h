@@ -293,6 +293,8 @@ int rbq_debug_copy_workspace(rbq_index* idx, void* hip_stream, const char* name,
  *                        logs the candidates it refines — 12 B each, up to 8192 per query in the calling stream's workspace — and the
  *                        tied query replays the log; rbq_debug_tie_log_stats)
  *   "scan_wave" 0/1/2    which scan kernel serves a call
+ *   "rank_ksplit" 0      never split the K loop of the ranking GEMM (default 1: calls of up to 256 queries split it 2-4 ways over
+ *                        grid.z, the parts added atomically to a cleared row; n > 1 forces n parts)
  * and two that are not result-neutral:
  *   "rerank" 0/1         the optional full-precision rerank (needs rbq_index_set_rerank_vectors)
  *   "debug_replica" r    which replica rbq_debug_copy_index / rbq_debug_copy_workspace read */

@@ -45,7 +45,8 @@ hipError_t launch_lat_front(const PrepParams& p, const RankParams& r, int device
     P.queries = p.queries; P.nq = p.nq; P.dim = p.dim; P.D = p.D; P.Dc = p.Dc; P.rotator = p.rotator; P.rot_blob = p.rot_blob;
     P.trunc = p.trunc; P.fac = p.fac; P.ex_bits = p.ex_bits; P.rot = p.rot; P.lut = p.lut; P.consts = p.consts;
     P.cent = r.cent; P.nlist = r.nlist; P.metric = r.metric; P.scores = r.scores;
-    P.rot_hi = p.rot_hi; P.rot_lo = p.rot_lo; P.scorers = r.scores ? (r.nlist + kLatLists - 1) / kLatLists : 0u;
+    P.rot_hi = p.rot_hi; P.rot_lo = p.rot_lo; P.scorers = (r.scores && !r.ksplit) ? (r.nlist + kLatLists - 1) / kLatLists : 0u;
+    P.zero_scores = r.ksplit > 1 ? r.scores : nullptr; // (split-K ranking GEMM behind this preparation: its parts are added to a zeroed row)
     const dim3 grid(lat_front_grid(P.scorers, p.nq));
     const size_t lds = (size_t)p.D * 4 * 2 + p.D / 2;
     if (probe_stage(0, reinterpret_cast<const void*>(&k_lat_front), grid, kThreads, lds)) return hipSuccess;
@@ -93,7 +94,7 @@ hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s) {
         return p.metric == 0 ? launch_rank_split<0, 2, 2, 2, 4>(p, grid, device, s) : launch_rank_split<1, 2, 2, 2, 4>(p, grid, device, s);
     }
     const uint32_t T = p.big ? 128u : 64u;
-    dim3 grid((p.nlist + T - 1) / T, (p.nq + T - 1) / T);
+    dim3 grid((p.nlist + T - 1) / T, (p.nq + T - 1) / T, p.split && p.ksplit > 1 ? p.ksplit : 1u); // (z: split-K, the row zeroed by the preparation)
     if (p.split) {
         if (p.metric == 0) return p.big ? launch_rank_split<0, 2, 1, 2, 4>(p, grid, device, s) : launch_rank_split<0, 1, 1, 2, 2>(p, grid, device, s);
         return p.big ? launch_rank_split<1, 2, 1, 2, 4>(p, grid, device, s) : launch_rank_split<1, 1, 1, 2, 2>(p, grid, device, s);

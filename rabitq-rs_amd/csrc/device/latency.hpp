@@ -38,6 +38,7 @@ struct LatFrontParams {
     int metric;
     float* scores;        // [nq][nlist] exact canonical scores (L2: squared distance; IP: dot)
     uint16_t *rot_hi, *rot_lo; // null, or the split-bf16 image of the rotated query (the ranking GEMM's operand: `scorers` = 0)
+    float* zero_scores;   // null, or the score rows [nq][nlist] to clear (a split-K ranking GEMM adds its parts to them)
     uint32_t scorers;     // G = ceil(nlist / 32) scoring workgroups per query, or 0: preparation only, the ranking GEMM follows (medium
                           // batches: a workgroup per query finishes a query's preparation in ~2/3 of the time one wave of k_prep_wave needs)
 };
@@ -155,6 +156,11 @@ __global__ __launch_bounds__(kThreads) void k_lat_front(const LatFrontParams P) 
             P.rot_hi[(size_t)q * D + i] = h;
             P.rot_lo[(size_t)q * D + i] = l;
         }
+    }
+    if (P.zero_scores) { // (the row a split-K ranking GEMM adds its parts to)
+        float* zr = P.zero_scores + (size_t)q * P.nlist;
+        if ((P.nlist & 3u) == 0u) for (uint32_t i = tid; i < P.nlist / 4; i += kThreads) reinterpret_cast<float4*>(zr)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        else for (uint32_t i = tid; i < P.nlist; i += kThreads) zr[i] = 0.0f;
     }
     if (tid == 0) { s_kmin = 0x7fffffff; s_kmax = (int)0x80000000; s_amin = 0; s_amax = 0; }
     __syncthreads();

@@ -61,6 +61,7 @@ struct RankParams {
     bool split;    // split-bf16 MFMA GEMM (else f32 MFMA)
     bool big;      // 128x128 tiles
     bool wide;     // 128x256 tiles (split-bf16 only): problems of at least 2048 such tiles
+    uint32_t ksplit = 0; // > 1: split-K over grid.z (split-bf16, 64 / 128 tiles): parts added atomically to a row the preparation zeroed
 };
 hipError_t launch_rank_exact(const RankParams& p, hipStream_t s);
 hipError_t launch_rank_gemm(const RankParams& p, int device, hipStream_t s);

@@ -167,7 +167,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16_db(const uint16_t* _
         sob[i] = 2 * BM * LDB + row * LDB + seg * 16;
     }
     u32x4 pah[NLA], pal[NLA], pbh[NLB], pbl[NLB];
-    const uint32_t nslab = D / BK;
+    // SPLIT-K (gridDim.z > 1; small batches, whose few tiles leave most of the chip idle while each walks all D / 32 slabs): workgroup z
+    // takes the slabs [z * per, (z + 1) * per) and ADDS its part of the score atomically to a row the preparation kernel zeroed
+    // (z = 0 also adds the norms).  The order of those additions is not fixed; the approximate score only feeds the shortlist, whose
+    // eps covers it (k_select_mfma), and every result is decided on exact scores.
+    const uint32_t nslab_all = D / BK, per_z = (nslab_all + gridDim.z - 1u) / gridDim.z, s_first = blockIdx.z * per_z;
+    if (s_first >= nslab_all) return; // (whole workgroup)
+    const uint32_t nslab = nslab_all - s_first < per_z ? nslab_all - s_first : per_z;
+    {
+        const size_t k_first = (size_t)s_first * BK * 2;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) { ga_h[i] += k_first; ga_l[i] += k_first; }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) { gb_h[i] += k_first; gb_l[i] += k_first; }
+    }
 #define RBQ_RANK_FETCH(S)                                                                                              \
     do {                                                                                                               \
         const size_t ko = (size_t)(S) * BK * 2;                                                                        \
@@ -268,7 +281,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_rank_bf16_db(const uint16_t* _
                 const uint32_t qi = q0 + wm * 32 * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (qi < nq && c < nlist) {
                     const float dot = acc[a][b][r];
-                    scores[(size_t)qi * nlist + c] = METRIC == 0 ? fmaf(-2.0f, dot, qn[a][r] + cn) : dot;
+                    if (gridDim.z == 1) scores[(size_t)qi * nlist + c] = METRIC == 0 ? fmaf(-2.0f, dot, qn[a][r] + cn) : dot;
+                    else atomicAdd(&scores[(size_t)qi * nlist + c], METRIC == 0 ? (blockIdx.z == 0 ? fmaf(-2.0f, dot, qn[a][r] + cn) : -2.0f * dot) : dot);
                 }
             }
         }
@@ -1018,7 +1032,9 @@ __global__ RBQ_SEL_BOUNDS void k_select_mfma(const SelectParams P, const SelectG
         return lo;
     };
     const QueryConsts qc = P.consts[q];
-    const float eps = (6.0f * (float)D * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + P.cnorm2_max) * 1.001f;
+    // (+ 16 x 2^-24: up to four split-K parts of the GEMM are added to the row in no fixed order, each addition rounding a sum of
+    // magnitude <= 2 (|q|^2 + |c|^2))
+    const float eps = ((6.0f * (float)D + 16.0f) * 5.9604645e-8f + 4.0f * 1.52587890625e-5f) * (qc.qnorm2 + P.cnorm2_max) * 1.001f;
     // ordered key of (the score of `key` moved 2 eps towards worse); 0xffffffff if that is not finite
     auto widen = [&](uint32_t key) -> uint32_t {
         int32_t k = (int32_t)(key ^ 0x80000000u);

@@ -117,6 +117,7 @@ struct Workspace {
     DevBuf queries, rot, lut, consts, scores, probe, wl, nstream, nvec, out_pack, filter, rot_hi, rot_lo, dead_skipped, heap_ws, key_window, audit_dead, tie_log;
     PinBuf h_in, h_out;      // rbq_search_batch: staging of one sub-batch
     hipEvent_t done = nullptr; // results of the sub-batch in flight have reached h_out / the caller's buffers
+    uint64_t call_nq = 0;       // queries of the WHOLE host call this launch chain belongs to (0: a device-entry call — its own nq counts)
     bool latency_first = false; // this launch chain belongs to a host call that waits for it (rbq_search_batch below kHostWaveMinQueries)
     void release() {
         for (DevBuf* b : {&queries, &rot, &lut, &consts, &scores, &probe, &wl, &nstream, &nvec, &rot_hi, &rot_lo, &out_pack, &filter, &dead_skipped,
@@ -232,6 +233,7 @@ constexpr uint64_t kHostWaveMinQueries = 4096;
 // (every query's pass over the table must stay a few microseconds: n_lists x D x 4 bytes x nq within kLatMaxBytes).
 constexpr uint64_t kLatMaxQueries = 4; // (measured, GIST-1M shape: 1 / 2 / 4 queries per call -12 / -10 / -12 us against prep + GEMM; 8: no gain)
 constexpr uint64_t kLatMaxBytes = 96ull << 20;
+constexpr uint64_t kSplitKMaxCallQueries = 256; // calls up to here split the ranking GEMM's K loop over grid.z
 constexpr uint64_t kPrepWgMaxQueries = 512; // up to here the preparation runs one WORKGROUP per query (latency.hpp without the scorers)
 
 // One device-resident copy of the index.
@@ -251,6 +253,7 @@ struct Replica {
     bool raw_borrowed = false;
     bool rerank = false;
     uint32_t host_lanes = 0, host_subbatch = 0, host_trace = 0; // rbq_debug_set_option: pipeline shape of rbq_search_batch (0 = default)
+    int rank_ksplit = 1;              // option rank_ksplit: 0 = never split the ranking GEMM's K loop, 1 = by batch size, n > 1 = forced
     int host_taper = 0;               // option host_taper: weights of a call's sub-batches (rbq_host_logic.hpp; A/B runs)
     uint32_t host_zero_copy_min = 5;  // option host_zero_copy_min: smallest call whose queries are read in place (up to 4 queries take the
                                       // latency-first front: a hundred workgroups per query would each read it over PCIe)
@@ -1179,6 +1182,18 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     unsigned long long* prof = (ix->profiling && ix->profile_counters) ? (unsigned long long*)ix->prof.p : nullptr;
     const uint32_t smask = ix->stage_mask;
     // small calls: prep + exact scores of every list in one launch (the ranking GEMM and its launch boundary are skipped)
+    // split-K of the ranking GEMM for batches whose tiles leave the chip idle (the rows are cleared by the workgroup-per-query preparation)
+    uint32_t ksplit = 1;
+    // (only when the whole CALL is small: the sub-batches of a 1024-query host call overlap each other, and the extra workgroups and
+    // atomics of a split GEMM then cost more than its shorter K loop saves — 277 -> 295 us per call, measured)
+    if (ix->rank_ksplit && ix->latency_path && nq <= kPrepWgMaxQueries && (w->call_nq ? w->call_nq : nq) <= kSplitKMaxCallQueries && ix->rotator != 0 &&
+        !ix->wg_prep && D % 16 == 0 && split_rank && !ix->exact_rank && !big_nprobe && smask == 0xfu) {
+        const uint32_t T = (!ix->small_rank_tiles && (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192 && ix->rank_tile != 64) || ix->rank_tile == 128 ? 128u : 64u;
+        const uint64_t tiles = (uint64_t)((nlist + T - 1) / T) * ((nq + T - 1) / T);
+        ksplit = tiles >= 512 ? 1u : (tiles >= 256 ? 2u : 4u);
+        while (ksplit > 1 && (D / 32) / ksplit < 6) ksplit >>= 1; // (at least six slabs per part)
+        if (ix->rank_ksplit > 1) ksplit = (uint32_t)ix->rank_ksplit; // (option: forced)
+    }
     const bool lat_front = ix->latency_path && nq <= kLatMaxQueries && ix->rotator != 0 && !ix->wg_prep && !ix->exact_rank && !big_nprobe &&
                            !ix->f32_rank && (uint64_t)nlist * D * 4 * nq <= kLatMaxBytes && D % 16 == 0 && smask == 0xfu;
     if (lat_front) {
@@ -1204,7 +1219,8 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
         // wave while the others build the LUT (latency.hpp, preparation only); full batches keep one wave per query (k_prep_wave)
         if (ix->latency_path && nq <= kPrepWgMaxQueries && ix->rotator != 0 && !ix->wg_prep && D % 16 == 0) {
             RankParams r;
-            r.metric = ix->metric; r.cent = nullptr; r.nlist = 0; r.D = D; r.nq = (uint32_t)nq; r.scores = nullptr;
+            r.metric = ix->metric; r.cent = nullptr; r.nlist = nlist; r.D = D; r.nq = (uint32_t)nq;
+            r.scores = ksplit > 1 ? (float*)w->scores.p : nullptr; r.ksplit = ksplit; // (split-K GEMM: this kernel clears the score rows)
             HIP_TRY(launch_lat_front(p, r, ix->device, stream));
         } else {
             HIP_TRY(launch_prep(p, ix->device, stream));
@@ -1214,7 +1230,7 @@ int search_device(Replica* ix, Workspace* w, const float* d_queries, uint64_t nq
     rp.metric = ix->metric; rp.rot = (const float*)w->rot.p; rp.rot_hi = (const uint16_t*)w->rot_hi.p; rp.rot_lo = (const uint16_t*)w->rot_lo.p;
     rp.cent = (const float*)ix->centroids.p; rp.cent_hi = (const uint16_t*)ix->cent_hi.p; rp.cent_lo = (const uint16_t*)ix->cent_lo.p;
     rp.consts = (const QueryConsts*)w->consts.p; rp.cnorm2 = (const float*)ix->cnorm2.p; rp.nq = (uint32_t)nq; rp.nlist = nlist; rp.D = D;
-    rp.scores = (float*)w->scores.p; rp.split = split_rank;
+    rp.scores = (float*)w->scores.p; rp.split = split_rank; rp.ksplit = ksplit;
     rp.big = !ix->small_rank_tiles && (uint64_t)((nlist + 127) / 128) * ((nq + 127) / 128) >= 192; // enough 128x128 tiles to fill the chip
     // option rank_tile: 0 = by problem size, 64 / 128 / 256 = forced (tests; A/B)
     rp.wide = ix->rank_tile == 256 || (ix->rank_tile == 0 && !ix->small_rank_tiles && (uint64_t)((nlist + 255) / 256) * ((nq + 127) / 128) >= 2048);
@@ -1463,8 +1479,10 @@ int search_host(Replica* ix, const float* queries, uint64_t nq, uint32_t query_d
         // which sub-batches of a call below kHostWaveMinQueries take the short-chain kernel: all (policy 0), only the LAST one — the chain
         // the caller actually waits for; the earlier ones overlap it — (1), none (2)
         w->latency_first = nq < kHostWaveMinQueries && (ix->host_wave_policy == 0 || (ix->host_wave_policy == 1 && j + 1 == nsub));
+        w->call_nq = nq;
         rc = search_device(ix, w, d_q, n, top_k, nprobe, d_filter, filter_nbits, k_ids, k_scores, k_counts, k_diag, w->stream);
         w->latency_first = false;
+        w->call_nq = 0;
         if (rc) return rc;
         if (ix->rerank) {
             if ((rc = w->h_out.ensure(op.total))) return rc;
@@ -1999,6 +2017,7 @@ int rbq_debug_set_option(rbq_index* h, const char* name, int value) {
         else if (!std::strcmp(name, "lazy_filter")) ix->lazy_filter = value != 0;
         else if (!std::strcmp(name, "host_zero_copy")) ix->host_zero_copy = value != 0;
         else if (!std::strcmp(name, "host_taper")) ix->host_taper = value;
+        else if (!std::strcmp(name, "rank_ksplit")) ix->rank_ksplit = value < 0 ? 0 : value;
         else if (!std::strcmp(name, "host_zero_copy_min")) ix->host_zero_copy_min = value > 0 ? (uint32_t)value : 1u;
         else if (!std::strcmp(name, "host_stage_helpers")) ix->host_stage_helpers = value != 0;
         else if (!std::strcmp(name, "rerank")) {
