@@ -193,3 +193,30 @@ def test_tie_log_seeded_sweep():
         q = np.ascontiguousarray(data[rng.integers(0, len(data), 24)].astype(np.float32))
         _compare(built, idx, q, top_k, nprobe)
         idx.close()
+
+
+# ---- split-K ranking GEMM of small calls (round 5) -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,nlist,bits,metric,top_k,nprobe", [
+    pytest.param(8000, 128, 70, 7, 0, 10, 16, id="d128_70_lists_L2"),
+    pytest.param(6000, 960, 48, 7, 0, 10, 12, id="d960_L2"),
+    pytest.param(6000, 960, 48, 3, 1, 10, 16, id="d960_3bit_IP"),
+    pytest.param(9000, 256, 1000, 7, 0, 10, 64, id="d256_1000_lists"),
+    pytest.param(5000, 768, 40, 7, 1, 100, 10, id="d768_IP_top100"),
+])
+def test_split_k_rank_gemm_small_calls(n, dim, nlist, bits, metric, top_k, nprobe):
+    """Calls of up to 256 queries split the K loop of the split-bf16 ranking GEMM over grid.z; the parts are added atomically (in no
+    fixed order) to score rows the preparation kernel cleared.  The approximate scores only feed the shortlist: ids, scores, counts and
+    diagnostics equal the oracle's with 2 and 4 forced parts, with the default choice and without the split, bit for bit between them."""
+    data, built = build_index(n=n, dim=dim, nlist=nlist, total_bits=bits, metric=metric, normalize=(metric == 1), seed=5700 + dim + nlist)
+    idx = rq.IvfRabitqIndex.from_built(built)
+    for nq in (5, 33, 64, 200):
+        q = make_dataset(nq, dim, max(nlist // 4, 1), 5750 + nq, normalize=(metric == 1))
+        outs = []
+        for ks in (1, 0, 2, 4):  # 1 = by batch size (the default), 0 = never, 2 / 4 = forced
+            idx.set_option("rank_ksplit", ks)
+            outs.append(_compare(built, idx, q, top_k, nprobe))
+        idx.set_option("rank_ksplit", 1)
+        for o in outs[1:]:
+            assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[2], outs[0][2]) and np.array_equal(o[1].view(np.uint32), outs[0][1].view(np.uint32))
+    assert idx.rank_fallbacks() == 0
+    idx.close()
